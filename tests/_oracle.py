@@ -1,0 +1,302 @@
+"""ctypes wrapper around oracle/_build/libzip_oracle.so (the CPU restatement).
+
+Test infrastructure: imported only by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB_PATH = os.path.join(ORACLE_DIR, "_build", "libzip_oracle.so")
+
+ORC_MAX_FL = 8
+ORC_OK, ORC_ERR_OVERFLOW, ORC_ERR_PARAM, ORC_ERR_PROOF, ORC_ERR_TRANSCRIPT = 0, -1, -2, -3, -4
+
+
+class Keccak(C.Structure):
+    _fields_ = [("st", C.c_uint64 * 25), ("buf", C.c_uint8 * 136), ("buflen", C.c_uint32)]
+
+
+class Field(C.Structure):
+    _fields_ = [
+        ("fl", C.c_uint32),
+        ("modulus", C.c_uint64 * ORC_MAX_FL),
+        ("r", C.c_uint64 * ORC_MAX_FL),
+        ("r2", C.c_uint64 * ORC_MAX_FL),
+        ("inv", C.c_uint64),
+        ("has_spare_bit", C.c_int),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("num_vars", C.c_uint32), ("row_len", C.c_uint32), ("num_rows", C.c_uint32),
+        ("codeword_len", C.c_uint32), ("rep", C.c_uint32), ("depth", C.c_uint32),
+        ("n_limbs", C.c_uint32), ("k_limbs", C.c_uint32), ("m_limbs", C.c_uint32),
+        ("perm1", C.POINTER(C.c_uint32)), ("perm2", C.POINTER(C.c_uint32)),
+        ("num_column_opening", C.c_uint32), ("num_proximity_testing", C.c_uint32),
+    ]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < max(
+            os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("zip_oracle.c", "zip_oracle.h"))
+    ):
+        subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_tr_get_u64.restype = C.c_uint64
+        _lib.orc_proof_len.restype = C.c_size_t
+    return _lib
+
+
+def int_to_limbs(v, n):
+    """Two's-complement little-endian limbs of a Python int."""
+    v &= (1 << (64 * n)) - 1
+    return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)]
+
+
+def limbs_to_int(limbs, signed=False):
+    v = 0
+    for i, l in enumerate(limbs):
+        v |= int(l) << (64 * i)
+    if signed and limbs is not None and (int(limbs[-1]) >> 63):
+        v -= 1 << (64 * len(limbs))
+    return v
+
+
+def _u64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def _u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def _u8p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def blake3(msg: bytes) -> bytes:
+    out = (C.c_uint8 * 32)()
+    rc = lib().orc_blake3_hash_block(msg, C.c_size_t(len(msg)), out)
+    assert rc == 0
+    return bytes(out)
+
+
+def keccak256(data: bytes, domain=1) -> bytes:
+    k = Keccak()
+    lib().orc_keccak_init(C.byref(k))
+    lib().orc_keccak_update(C.byref(k), data, C.c_size_t(len(data)))
+    out = (C.c_uint8 * 32)()
+    lib().orc_keccak_finalize_copy(C.byref(k), C.c_uint8(domain), out)
+    return bytes(out)
+
+
+def new_transcript() -> Keccak:
+    k = Keccak()
+    lib().orc_keccak_init(C.byref(k))
+    return k
+
+
+def absorb(k: Keccak, data: bytes):
+    lib().orc_keccak_update(C.byref(k), data, C.c_size_t(len(data)))
+
+
+def make_field(modulus: int, fl: int) -> Field:
+    f = Field()
+    m = (C.c_uint64 * fl)(*int_to_limbs(modulus, fl))
+    rc = lib().orc_field_new(C.byref(f), fl, m)
+    assert rc == 0, rc
+    return f
+
+
+def field_elems(values, fl):
+    """Python ints (already Montgomery / raw residues) -> uint64 array [n, fl]."""
+    a = np.zeros((len(values), fl), dtype=np.uint64)
+    for i, v in enumerate(values):
+        a[i] = int_to_limbs(v, fl)
+    return a
+
+
+def field_from_i64(f: Field, v: int) -> int:
+    out = (C.c_uint64 * ORC_MAX_FL)()
+    lib().orc_field_from_i64(C.byref(f), C.c_int64(v), out)
+    return limbs_to_int(out[: f.fl])
+
+
+def field_mul(f: Field, a: int, b: int) -> int:
+    aa = (C.c_uint64 * ORC_MAX_FL)(*int_to_limbs(a, f.fl))
+    bb = (C.c_uint64 * ORC_MAX_FL)(*int_to_limbs(b, f.fl))
+    lib().orc_field_mul(C.byref(f), aa, bb)
+    return limbs_to_int(aa[: f.fl])
+
+
+def field_add(f: Field, a: int, b: int) -> int:
+    aa = (C.c_uint64 * ORC_MAX_FL)(*int_to_limbs(a, f.fl))
+    bb = (C.c_uint64 * ORC_MAX_FL)(*int_to_limbs(b, f.fl))
+    lib().orc_field_add(C.byref(f), aa, bb)
+    return limbs_to_int(aa[: f.fl])
+
+
+def get_challenge(k: Keccak, f: Field) -> int:
+    out = (C.c_uint64 * ORC_MAX_FL)()
+    lib().orc_tr_get_challenge(C.byref(k), C.byref(f), out)
+    return limbs_to_int(out[: f.fl])
+
+
+def build_eq_x_r(f: Field, r: np.ndarray) -> np.ndarray:
+    nvars = r.shape[0]
+    out = np.zeros((1 << nvars, f.fl), dtype=np.uint64)
+    rc = lib().orc_build_eq_x_r(C.byref(f), _u64p(np.ascontiguousarray(r)), nvars, _u64p(out))
+    assert rc == 0
+    return out
+
+
+def shuffle_perm(seed: int, length: int) -> np.ndarray:
+    perm = np.zeros(length, dtype=np.uint32)
+    lib().orc_shuffle_seeded_perm(C.c_uint64(seed), length, _u32p(perm))
+    return perm
+
+
+class Zip:
+    """Geometry + permutations for one polynomial size (RaaCode::new + setup)."""
+
+    def __init__(self, num_vars, perm1=None, perm2=None, seeds=(1, 2), n_limbs=1, rep=2):
+        self.p = Params()
+        probe = Params()
+        lib().orc_params_init(C.byref(probe), num_vars, n_limbs, rep, None, None)
+        cw = probe.codeword_len
+        self.perm1 = np.ascontiguousarray(perm1 if perm1 is not None else shuffle_perm(seeds[0], cw), dtype=np.uint32)
+        self.perm2 = np.ascontiguousarray(perm2 if perm2 is not None else shuffle_perm(seeds[1], cw), dtype=np.uint32)
+        rc = lib().orc_params_init(C.byref(self.p), num_vars, n_limbs, rep, _u32p(self.perm1), _u32p(self.perm2))
+        if rc != 0:
+            raise ValueError(f"orc_params_init failed: {rc}")
+        for name in ("num_vars", "row_len", "num_rows", "codeword_len", "rep", "depth", "n_limbs", "k_limbs", "m_limbs"):
+            setattr(self, name, getattr(self.p, name))
+        self.tree_hashes = (2 << self.depth) - 1
+
+    def encode_row(self, row, in_limbs=None, out_limbs=None):
+        in_limbs = in_limbs or self.n_limbs
+        out_limbs = out_limbs or self.k_limbs
+        row = np.ascontiguousarray(row).view(np.uint64).reshape(-1)
+        out = np.zeros((self.codeword_len, out_limbs), dtype=np.uint64)
+        rc = lib().orc_raa_encode_row(_u64p(row), in_limbs, self.row_len, self.rep, _u32p(self.perm1),
+                                      _u32p(self.perm2), _u64p(out), out_limbs)
+        return rc, out
+
+    def commit(self, evals, merkle=True):
+        evals = np.ascontiguousarray(evals, dtype=np.int64)
+        assert evals.size == self.num_rows * self.row_len
+        rows = np.zeros((self.num_rows * self.codeword_len, self.k_limbs), dtype=np.uint64)
+        layers = roots = None
+        if merkle:
+            layers = np.zeros((self.num_rows, self.tree_hashes, 32), dtype=np.uint8)
+            roots = np.zeros((self.num_rows, 32), dtype=np.uint8)
+        rc = lib().orc_commit(C.byref(self.p), _u64p(evals.view(np.uint64)), _u64p(rows),
+                              _u8p(layers) if merkle else None, _u8p(roots) if merkle else None)
+        assert rc == 0, rc
+        return rows, layers, roots
+
+    def proof_len(self, fl):
+        return lib().orc_proof_len(C.byref(self.p), fl)
+
+    def combine_rows_int(self, coeffs, evals):
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.int64)
+        evals = np.ascontiguousarray(evals, dtype=np.int64)
+        out = np.zeros((self.row_len, self.m_limbs), dtype=np.uint64)
+        rc = lib().orc_combine_rows_int(_u64p(coeffs.view(np.uint64)), 1, _u64p(evals.view(np.uint64)), 1,
+                                        self.num_rows, self.row_len, _u64p(out), self.m_limbs)
+        return rc, out
+
+    def combine_rows_field(self, f: Field, q0, evals):
+        evals = np.ascontiguousarray(evals, dtype=np.int64)
+        q0 = np.ascontiguousarray(q0, dtype=np.uint64)
+        out = np.zeros((self.row_len, f.fl), dtype=np.uint64)
+        lib().orc_combine_rows_field(C.byref(f), _u64p(q0), _u64p(evals.view(np.uint64)), 1,
+                                     self.num_rows, self.row_len, _u64p(out))
+        return out
+
+    def open(self, f: Field, evals, rows, layers, point, fs: Keccak):
+        evals = np.ascontiguousarray(evals, dtype=np.int64)
+        point = np.ascontiguousarray(point, dtype=np.uint64)
+        cap = self.proof_len(f.fl)
+        proof = np.zeros(cap, dtype=np.uint8)
+        plen = C.c_size_t(0)
+        cols = np.zeros(self.p.num_column_opening, dtype=np.uint32)
+        coeffs = np.zeros(self.num_rows, dtype=np.int64)
+        rc = lib().orc_open(C.byref(self.p), C.byref(f), _u64p(evals.view(np.uint64)), _u64p(rows),
+                            _u8p(layers), _u64p(point), C.byref(fs), _u8p(proof), C.c_size_t(cap),
+                            C.byref(plen), _u32p(cols), _u64p(coeffs.view(np.uint64)))
+        assert rc == 0, rc
+        assert plen.value == cap, (plen.value, cap)
+        return proof, cols, coeffs
+
+    def verify(self, f: Field, roots, point, eval_mont, proof, fs: Keccak = None, check_merkle=True):
+        fs = fs or new_transcript()
+        point = np.ascontiguousarray(point, dtype=np.uint64)
+        ev = np.array(int_to_limbs(eval_mont, f.fl), dtype=np.uint64)
+        proof = np.ascontiguousarray(proof, dtype=np.uint8)
+        roots = np.ascontiguousarray(roots, dtype=np.uint8)
+        return lib().orc_verify(C.byref(self.p), C.byref(f), _u8p(roots), _u64p(point), _u64p(ev),
+                                C.byref(fs), _u8p(proof), C.c_size_t(proof.size), int(check_merkle))
+
+    def mle_eval(self, f: Field, evals, point) -> int:
+        evals = np.ascontiguousarray(evals, dtype=np.int64)
+        point = np.ascontiguousarray(point, dtype=np.uint64)
+        out = (C.c_uint64 * ORC_MAX_FL)()
+        lib().orc_mle_eval_field(C.byref(f), _u64p(evals.view(np.uint64)), 1, self.num_vars, _u64p(point), out)
+        return limbs_to_int(out[: f.fl])
+
+
+def merkle_tree(depth, leaves: np.ndarray):
+    leaves = np.ascontiguousarray(leaves, dtype=np.uint64)
+    leaf_limbs = leaves.shape[1]
+    layers = np.zeros(((2 << depth) - 1, 32), dtype=np.uint8)
+    rc = lib().orc_merkle_tree(depth, _u64p(leaves), leaf_limbs, _u8p(layers))
+    assert rc == 0
+    return layers
+
+
+def merkle_path(depth, layers, leaf):
+    path = np.zeros((depth, 32), dtype=np.uint8)
+    lib().orc_merkle_path(depth, _u8p(np.ascontiguousarray(layers)), leaf, _u8p(path))
+    return path
+
+
+def merkle_verify(depth, path, root, leaf_limbs_arr, leaf_index):
+    leaf = np.ascontiguousarray(leaf_limbs_arr, dtype=np.uint64)
+    return lib().orc_merkle_verify(depth, _u8p(np.ascontiguousarray(path)), _u8p(np.ascontiguousarray(root)),
+                                   _u64p(leaf), leaf.size, leaf_index)
+
+
+def point_to_field(f: Field, ints):
+    """`vec![..i64..].map_to_field(config)` -> uint64 [n, fl] Montgomery limbs."""
+    return field_elems([field_from_i64(f, int(v)) for v in ints], f.fl)
+
+
+def splitmix64(seed, n):
+    """Synthetic witness generator shared by tests and bench."""
+    out = np.empty(n, dtype=np.uint64)
+    x = np.uint64(seed)
+    idx = np.arange(1, n + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = x + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    out[:] = z
+    return out.view(np.int64)
