@@ -1,0 +1,177 @@
+/*
+ * zip_hip.h -- C ABI of libzip_hip.so: the MI355X (gfx950) implementation of the
+ * Zip PCS commit/open hot path of NethermindEth/zinc.
+ *
+ * This is the drop-in boundary.  A thin Rust shim inside
+ *   zinc::zip::pcs::MultilinearZip::{commit, commit_no_merkle, encode_rows, open}
+ *   (src/zip/pcs/commit.rs:50,104,158; src/zip/pcs/open_z.rs:22)
+ * binds these symbols (see INTEGRATION.md for the `extern "C"` block) and keeps
+ * ZincProver / ZincVerifier unchanged.  Everything that is sequential and tiny
+ * stays on the host side of the boundary: the Keccak Fiat-Shamir transcript
+ * (src/transcript.rs), the rand-based permutation expansion
+ * (src/zip/utils.rs:139-142), the eq-tensor q_0 (src/zip/pcs/utils.rs:279-292) and
+ * the absorption of the evaluation row (src/zip/pcs_transcript.rs:107-113).
+ *
+ * Conventions
+ *  - plain C types only; every call returns int32 (ZIP_OK == 0, negative = error)
+ *  - no exceptions / unwinding cross the boundary; zip_strerror() names a code and
+ *    zip_ctx_last_error() returns the detailed message of the last failing call
+ *  - one zip_ctx per GPU and per geometry; one process per GPU (multi-GPU runs
+ *    give every rank its own ctx with a row shard, and exchange roots / partial
+ *    rows with RCCL above this ABI)
+ *  - all work is enqueued on the ctx's HIP stream; calls that write HOST memory
+ *    return after the data has landed, calls that only touch DEVICE memory return
+ *    asynchronously (use zip_ctx_synchronize)
+ *  - integers are little-endian arrays of 64-bit limbs in two's complement
+ *    (src/field/int.rs:23-25); field elements are little-endian limb arrays of the
+ *    Montgomery representation (src/field.rs:24-32)
+ *  - a pointer argument with a zip_mem_kind may be host or device memory
+ */
+#ifndef ZIP_HIP_H
+#define ZIP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZIP_HIP_ABI_VERSION 1
+
+/* status codes */
+#define ZIP_OK 0
+#define ZIP_ERR_INVALID_PARAM (-1) /* zip::Error::InvalidPcsParam (src/zip/pcs/utils.rs:17-39) and the
+                                      RaaCode width assertion (src/zip/code_raa.rs:68-72) */
+#define ZIP_ERR_SHAPE (-2)         /* where the reference panics on a shape mismatch (commit.rs:56-63) */
+#define ZIP_ERR_HIP (-3)           /* a HIP runtime call failed */
+#define ZIP_ERR_NO_DEVICE (-4)     /* no usable gfx950 device: there is NO CPU fallback */
+#define ZIP_ERR_UNSUPPORTED (-5)   /* geometry outside what the kernels implement */
+#define ZIP_ERR_ALLOC (-6)
+#define ZIP_ERR_NULL (-7)
+
+typedef enum { ZIP_MEM_HOST = 0, ZIP_MEM_DEVICE = 1 } zip_mem_kind;
+
+typedef struct zip_ctx zip_ctx;
+typedef struct zip_commitment zip_commitment;
+
+/* Geometry of one polynomial size: what RaaCode::new (src/zip/code_raa.rs:35-86) and
+ * MultilinearZip::setup (src/zip/pcs/structs.rs:79-91) compute, plus the two
+ * permutations that shuffle_seeded(perm_k_seed) applies (out[j] = in[perm[j]]). */
+typedef struct {
+    uint32_t num_vars;     /* log2(poly_size) */
+    uint32_t row_len;      /* next_pow2(isqrt(poly_size))            code_raa.rs:43  */
+    uint32_t num_rows;     /* next_pow2(poly_size / row_len)         structs.rs:82   */
+    uint32_t codeword_len; /* row_len * rep                          code_raa.rs:113 */
+    uint32_t rep;          /* repetition factor (power of two)       code.rs:235-237 */
+    uint32_t n_limbs;      /* ZipTypes::N limbs, must be 1           traits/types.rs:225-240 */
+    uint32_t k_limbs;      /* ZipTypes::K limbs, must be 4 */
+    uint32_t m_limbs;      /* ZipTypes::M limbs, must be 8 */
+    const uint32_t *perm1; /* HOST, codeword_len entries, a permutation of [0, codeword_len) */
+    const uint32_t *perm2; /* HOST, codeword_len entries */
+    int32_t device;        /* HIP device ordinal */
+    uint32_t row_begin;    /* first row of this ctx's shard (0 for a whole polynomial) */
+    uint32_t row_count;    /* rows in the shard; 0 means num_rows */
+} zip_params;
+
+/* Field configuration (src/field/config.rs:30-50).  Only the modulus crosses the
+ * boundary; R^2 and -q^-1 mod 2^64 are recomputed (config.rs:174-214). */
+typedef struct {
+    uint32_t limbs;      /* FIELD_LIMBS: 2, 3 or 4 */
+    uint64_t modulus[8]; /* little-endian limbs, odd */
+} zip_field;
+
+int32_t zip_abi_version(void);
+const char *zip_strerror(int32_t code);
+/* number of visible HIP devices (0 when there is no GPU); never initialises a context */
+int32_t zip_device_count(void);
+
+int32_t zip_ctx_create(const zip_params *params, zip_ctx **out);
+void zip_ctx_destroy(zip_ctx *ctx);
+const char *zip_ctx_last_error(const zip_ctx *ctx);
+int32_t zip_ctx_synchronize(zip_ctx *ctx);
+/* the ctx's hipStream_t, for callers that order their own device work against it */
+void *zip_ctx_stream(zip_ctx *ctx);
+
+/* ---- commit ------------------------------------------------------------------
+ * MultilinearZip::commit (commit.rs:50-87) when with_merkle != 0,
+ * commit_no_merkle / encode_rows (commit.rs:104-119,158-183) when with_merkle == 0.
+ * evals: the shard's row_count * row_len witness values (Int<1>), row-major.
+ * n_evals must equal row_count * row_len (ZIP_ERR_SHAPE otherwise, commit.rs:56-63).
+ * roots_out: HOST, row_count * 32 bytes, may be NULL.
+ * The returned handle owns the device-resident MultilinearZipData. */
+int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
+                   int32_t with_merkle, uint8_t *roots_out, zip_commitment **out);
+void zip_commitment_free(zip_commitment *c);
+
+/* Device views of the handle (zero-copy interop).  rows: row_count*cw*4 u64.
+ * layers: per row 2*cw hashes of 32 B (level k at hash offset 2cw-(2cw>>k), root at
+ * 2cw-2, last slot padding).  roots: row_count*32 B.  Any out pointer may be NULL. */
+int32_t zip_commitment_device_ptrs(zip_commitment *c, uint64_t **rows, uint8_t **layers, uint8_t **roots);
+/* Host copies in the reference's layout: rows_out row_count*cw*k_limbs u64
+ * (MultilinearZipData.rows), layers_out row_count * ((2<<depth)-2) * 32 B
+ * (MerkleTree.layers of every row, root popped), roots_out row_count*32 B. */
+int32_t zip_commit_download(zip_commitment *c, uint64_t *rows_out, uint8_t *layers_out, uint8_t *roots_out);
+/* Build a handle from host data in the layout above (the reference's tests mutate
+ * MultilinearZipData before opening: commit.rs:389, open_z.rs:230-241). */
+int32_t zip_commitment_upload(zip_ctx *ctx, const uint64_t *rows, const uint8_t *layers, const uint8_t *roots,
+                              zip_commitment **out);
+
+/* ---- open ----------------------------------------------------------------------
+ * The three parts of MultilinearZip::open (open_z.rs:22-40) with the transcript
+ * outputs as inputs: coeffs = get_integer_challenges(num_rows) (open_z.rs:104),
+ * cols = the squeezed column indices (open_z.rs:118), q0_mont = the eq tensor of the
+ * last log2(num_rows) point coordinates (pcs/utils.rs:279-292).  Shard-local slices
+ * (row_count entries) when the ctx is a row shard. */
+
+/* prove_testing_phase, proximity row (open_z.rs:103-112): uprime_out row_len * m_limbs u64. */
+int32_t zip_open_testing(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_kind, const int64_t *coeffs,
+                         uint64_t *uprime_out, zip_mem_kind out_kind);
+/* open_merkle_trees_for_column for n_cols columns (open_z.rs:116-120,124-143): wire_out gets
+ * n_cols * row_count * (8*k_limbs + 8 + 32*depth) bytes in proof-stream format. */
+int32_t zip_open_columns(zip_commitment *c, const uint32_t *cols, uint32_t n_cols, uint8_t *wire_out,
+                         zip_mem_kind out_kind);
+/* prove_evaluation_phase (open_z.rs:62-91): row_out row_len * field->limbs u64 (Montgomery limbs).
+ * When num_rows == 1 q0_mont is ignored and row_out = map_to_field(evals). */
+int32_t zip_open_eval(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_kind, const uint64_t *q0_mont,
+                      const zip_field *field, uint64_t *row_out, zip_mem_kind out_kind);
+/* proof length in bytes for n_cols openings (commit.rs:712-737) */
+size_t zip_proof_len(const zip_ctx *ctx, uint32_t n_cols, uint32_t field_limbs);
+/* Whole proof stream of open() in one call, witness read once:
+ *   [u' : row_len*m_limbs*8 B, only if num_rows > 1] [n_cols column openings] [row_len field
+ *   elements, big-endian bytes of the Montgomery value (pcs_transcript.rs:107-113)].
+ * The caller still absorbs the field elements into its transcript afterwards.
+ * Only valid on an unsharded ctx. */
+int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kind, const int64_t *coeffs,
+                 const uint32_t *cols, uint32_t n_cols, const uint64_t *q0_mont, const zip_field *field,
+                 uint8_t *proof_out, zip_mem_kind out_kind);
+
+/* Row-sharded open: exact sum of n_parts partial results (after an all-gather).
+ * uparts: n_parts * row_len * m_limbs u64 or NULL; fparts: n_parts * row_len * limbs u64 or NULL.
+ * All pointers DEVICE memory. */
+int32_t zip_sum_partials(zip_ctx *ctx, const uint64_t *uparts, const uint64_t *fparts, uint32_t n_parts,
+                         const zip_field *field, uint64_t *uprime_out, uint64_t *row_out);
+
+/* ---- standalone Merkle tree --------------------------------------------------------
+ * MerkleTree::new (pcs/utils.rs:74-85) over num_trees * 2^depth leaves of leaf_limbs
+ * (1..8) limbs each.  layers_out: num_trees * ((2<<depth)-1) * 32 B, root last
+ * (the reference pops it into .root).  Buffers HOST or DEVICE per kind. */
+int32_t zip_merkle_trees(int32_t device, const uint64_t *leaves, uint32_t leaf_limbs, uint32_t depth,
+                         uint32_t num_trees, zip_mem_kind kind, uint8_t *layers_out);
+
+/* ---- measurement hooks ---------------------------------------------------------------
+ * With profiling on, every kernel launch is bracketed by HIP events on the ctx stream.
+ * zip_ctx_profile_read synchronises, then fills up to cap entries (kernel name, launch
+ * count, total ms) and resets the counters; returns the number of distinct kernels. */
+typedef struct {
+    const char *name;
+    uint32_t launches;
+    float total_ms;
+} zip_kernel_time;
+int32_t zip_ctx_set_profiling(zip_ctx *ctx, int32_t on);
+int32_t zip_ctx_profile_read(zip_ctx *ctx, zip_kernel_time *out, uint32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZIP_HIP_H */

@@ -175,16 +175,19 @@ def shuffle_perm(seed: int, length: int) -> np.ndarray:
 class Zip:
     """Geometry + permutations for one polynomial size (RaaCode::new + setup)."""
 
-    def __init__(self, num_vars, perm1=None, perm2=None, seeds=(1, 2), n_limbs=1, rep=2):
+    def __init__(self, num_vars, perm1=None, perm2=None, seeds=(1, 2), n_limbs=1, rep=2, geometry=None):
         self.p = Params()
         probe = Params()
         lib().orc_params_init(C.byref(probe), num_vars, n_limbs, rep, None, None)
-        cw = probe.codeword_len
+        cw = geometry[2] if geometry else probe.codeword_len
         self.perm1 = np.ascontiguousarray(perm1 if perm1 is not None else shuffle_perm(seeds[0], cw), dtype=np.uint32)
         self.perm2 = np.ascontiguousarray(perm2 if perm2 is not None else shuffle_perm(seeds[1], cw), dtype=np.uint32)
         rc = lib().orc_params_init(C.byref(self.p), num_vars, n_limbs, rep, _u32p(self.perm1), _u32p(self.perm2))
         if rc != 0:
             raise ValueError(f"orc_params_init failed: {rc}")
+        if geometry:  # (row_len, num_rows, codeword_len): any consistent shape, e.g. a row shard
+            self.p.row_len, self.p.num_rows, self.p.codeword_len = geometry
+            self.p.depth = (geometry[2] - 1).bit_length() if geometry[2] > 1 else 0
         for name in ("num_vars", "row_len", "num_rows", "codeword_len", "rep", "depth", "n_limbs", "k_limbs", "m_limbs"):
             setattr(self, name, getattr(self.p, name))
         self.tree_hashes = (2 << self.depth) - 1

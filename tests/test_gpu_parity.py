@@ -1,0 +1,274 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on
+identical inputs -- bit-exact (integer / byte work).  Needs a real MI355X."""
+import numpy as np
+import pytest
+
+import _oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+BENCH_MODULUS = 106319353542452952636349991594949358997917625194731877894581586278529202198383
+TEST_MODULUS_2 = 57316695564490278656402085503
+MOD_NO_SPARE = (1 << 256) - 189  # benches/spartan_benches.rs:134-137
+MOD_3LIMB = (1 << 190) - 11 * (1 << 64) - 59  # not necessarily prime; arithmetic is ring arithmetic either way
+
+
+@pytest.fixture(scope="module")
+def cabi():
+    from zinc_amd import cabi as m
+
+    if m.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu tests must run on the MI355X box")
+    return m
+
+
+def _ctx(cabi, z, **kw):
+    return cabi.ZipContext(z.num_vars, z.perm1, z.perm2, geometry_override=(z.row_len, z.num_rows, z.codeword_len), **kw)
+
+
+def _witness(num_vars, seed=0, small=False):
+    n = 1 << num_vars
+    if small:
+        return np.random.default_rng(seed).integers(-128, 128, size=n, dtype=np.int64)
+    w = orc.splitmix64(0x5A494E43 + seed, n).copy()
+    # force the extremes in (sign handling, carries)
+    w[: min(n, 4)] = np.array([-(2**63), 2**63 - 1, -1, 0], dtype=np.int64)[: min(n, 4)]
+    return w
+
+
+# every kernel variant: E=1 (cw<=64), E=2 (128), E=4 (256), E=8 (>=512); odd num_vars; single row
+@pytest.mark.parametrize("num_vars", [0, 1, 2, 3, 5, 6, 9, 10, 12, 13, 14, 16, 18])
+def test_commit_bit_exact(cabi, num_vars):
+    z = orc.Zip(num_vars)
+    evals = _witness(num_vars)
+    rows_o, layers_o, roots_o = z.commit(evals)
+    ctx = _ctx(cabi, z)
+    com, roots = ctx.commit(evals)
+    rows, layers, roots_d = com.download()
+    assert np.array_equal(rows, rows_o)
+    assert np.array_equal(roots, roots_o) and np.array_equal(roots_d, roots_o)
+    assert np.array_equal(layers, layers_o[:, :-1, :])  # reference layers have the root popped
+    # commit_no_merkle / encode_rows (commit.rs:104-119)
+    com2, r2 = ctx.commit(evals, with_merkle=False)
+    assert r2 is None
+    assert np.array_equal(com2.download()[0], rows_o)
+    # deterministic (commit.rs:253-283)
+    com3, roots3 = ctx.commit(evals)
+    assert np.array_equal(roots3, roots_o)
+
+
+def test_commit_2pow20_bit_exact(cabi):
+    """BASELINE config 2: commit at 2^20 coefficients, every byte against the oracle."""
+    z = orc.Zip(20)
+    evals = _witness(20)
+    rows_o, layers_o, roots_o = z.commit(evals)
+    ctx = _ctx(cabi, z)
+    com, roots = ctx.commit(evals)
+    rows, layers, _ = com.download()
+    assert np.array_equal(roots, roots_o)
+    assert np.array_equal(rows, rows_o)
+    assert np.array_equal(layers, layers_o[:, :-1, :])
+
+
+def test_commit_device_resident_input(cabi):
+    torch = pytest.importorskip("torch")
+    z = orc.Zip(12)
+    evals = _witness(12)
+    ctx = _ctx(cabi, z)
+    d = torch.from_numpy(evals).cuda()
+    com, roots = ctx.commit(d)
+    assert np.array_equal(roots, z.commit(evals)[2])
+
+
+def test_commit_large_codeword_global_t2_path(cabi):
+    """cw = 16384 (the 2^26 geometry) uses the variant that parks t2 in the output row."""
+    z = orc.Zip(16, geometry=(8192, 8, 16384))
+    evals = _witness(16)
+    rows_o, layers_o, roots_o = z.commit(evals)
+    ctx = _ctx(cabi, z)
+    com, roots = ctx.commit(evals)
+    rows, layers, _ = com.download()
+    assert np.array_equal(rows, rows_o)
+    assert np.array_equal(layers, layers_o[:, :-1, :])
+    assert np.array_equal(roots, roots_o)
+
+
+def test_commit_shape_and_param_errors(cabi):
+    z = orc.Zip(8)
+    ctx = _ctx(cabi, z)
+    with pytest.raises(cabi.ZipError) as e:  # commit.rs:56-63 panics; the ABI reports ZIP_ERR_SHAPE
+        ctx.commit(np.zeros(100, dtype=np.int64))
+    assert e.value.code == cabi.ZIP_ERR_SHAPE
+    bad = z.perm1.copy()
+    bad[0] = bad[1]
+    with pytest.raises(cabi.ZipError) as e:
+        cabi.ZipContext(8, bad, z.perm2)
+    assert e.value.code == cabi.ZIP_ERR_INVALID_PARAM
+    with pytest.raises(cabi.ZipError) as e:  # K must be Int<4N>
+        cabi.ZipContext(8, z.perm1, z.perm2, k_limbs=2)
+    assert e.value.code == cabi.ZIP_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("num_vars", [2, 3, 8, 9, 12, 16])
+def test_open_testing_bit_exact(cabi, num_vars):
+    z = orc.Zip(num_vars)
+    evals = _witness(num_vars)
+    coeffs = orc.splitmix64(77, z.num_rows).copy()
+    coeffs[:2] = [-(2**63), 2**63 - 1][: min(2, z.num_rows)]
+    rc, expect = z.combine_rows_int(coeffs, evals)
+    assert rc == 0
+    ctx = _ctx(cabi, z)
+    got = ctx.open_testing(evals, coeffs)
+    assert np.array_equal(got, expect)
+
+
+@pytest.mark.parametrize("modulus,fl", [(BENCH_MODULUS, 4), (TEST_MODULUS_2, 2), (MOD_NO_SPARE, 4), (MOD_3LIMB, 3)])
+@pytest.mark.parametrize("num_vars", [3, 8, 9, 14])
+def test_open_eval_bit_exact(cabi, num_vars, modulus, fl):
+    z = orc.Zip(num_vars)
+    f = orc.make_field(modulus, fl)
+    evals = _witness(num_vars)
+    rng = np.random.default_rng(num_vars)
+    q0_vals = [int.from_bytes(rng.bytes(8 * fl), "little") % modulus for _ in range(z.num_rows)]
+    q0_vals[0] = modulus - 1
+    q0 = orc.field_elems(q0_vals, fl)
+    expect = z.combine_rows_field(f, q0, evals)
+    ctx = _ctx(cabi, z)
+    got = ctx.open_eval(evals, q0, cabi.make_field(modulus, fl))
+    assert np.array_equal(got, expect)
+
+
+def test_open_eval_single_row_is_map_to_field(cabi):
+    z = orc.Zip(0)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    ctx = _ctx(cabi, z)
+    for w in (-5, 0, 2**63 - 1, -(2**63)):
+        got = ctx.open_eval(np.array([w], dtype=np.int64), None, cabi.make_field(BENCH_MODULUS, 4))
+        assert orc.limbs_to_int(got[0]) == orc.field_from_i64(f, w)
+
+
+@pytest.mark.parametrize("num_vars", [3, 8, 12, 16])
+def test_open_columns_wire_format(cabi, num_vars):
+    z = orc.Zip(num_vars)
+    evals = _witness(num_vars)
+    rows_o, layers_o, roots_o = z.commit(evals)
+    ctx = _ctx(cabi, z)
+    com, _ = ctx.commit(evals)
+    rng = np.random.default_rng(1)
+    cols = rng.integers(0, z.codeword_len, size=37, dtype=np.uint32)
+    cols[:3] = [0, z.codeword_len - 1, cols[3]]  # edges + a duplicate
+    wire = com.open_columns(cols)
+    per_col = z.num_rows * (32 + 8 + 32 * z.depth)
+    assert wire.size == cols.size * per_col
+    rows3 = rows_o.reshape(z.num_rows, z.codeword_len, 4)
+    for i, c in enumerate(cols):
+        blk = wire[i * per_col:(i + 1) * per_col]
+        assert blk[: z.num_rows * 32].tobytes() == rows3[:, c, :].astype("<u8").tobytes()
+        rec = blk[z.num_rows * 32:].reshape(z.num_rows, 8 + 32 * z.depth)
+        for r in range(z.num_rows):
+            assert int.from_bytes(rec[r, :8].tobytes(), "big") == z.depth
+            assert rec[r, 8:].tobytes() == orc.merkle_path(z.depth, layers_o[r], int(c)).tobytes()
+
+
+@pytest.mark.parametrize("num_vars,modulus,fl", [(8, BENCH_MODULUS, 4), (8, TEST_MODULUS_2, 2), (9, BENCH_MODULUS, 4),
+                                                 (3, TEST_MODULUS_2, 2), (0, BENCH_MODULUS, 4), (14, BENCH_MODULUS, 4)])
+def test_full_open_proof_equals_oracle_and_verifies(cabi, num_vars, modulus, fl):
+    """The proof bytes of MultilinearZip::open on identical transcripts, then the
+    oracle's verifier (src/zip/pcs/verify_z.rs) accepts the GPU proof."""
+    z = orc.Zip(num_vars)
+    f = orc.make_field(modulus, fl)
+    evals = _witness(num_vars, small=(fl == 2))
+    rng = np.random.default_rng(3)
+    point_i = rng.integers(-100, 100, size=num_vars, dtype=np.int64)
+    point = orc.point_to_field(f, point_i) if num_vars else np.zeros((0, fl), dtype=np.uint64)
+    rows_o, layers_o, roots_o = z.commit(evals)
+    fs = orc.new_transcript()
+    proof_o, cols, coeffs = z.open(f, evals, rows_o, layers_o, point, fs)
+
+    ctx = _ctx(cabi, z)
+    com, roots = ctx.commit(evals)
+    assert np.array_equal(roots, roots_o)
+    lr = z.num_rows.bit_length() - 1
+    q0 = orc.build_eq_x_r(f, point[num_vars - lr:]) if lr else None
+    proof = com.open(evals, coeffs if z.num_rows > 1 else None, cols, q0, cabi.make_field(modulus, fl))
+    assert proof.size == proof_o.size == z.proof_len(fl)
+    assert np.array_equal(proof, proof_o)
+    ev = z.mle_eval(f, evals, point)
+    assert z.verify(f, roots, point, ev, proof) == 0
+
+
+def test_open_from_uploaded_and_mutated_commitment(cabi):
+    """The reference's tests mutate MultilinearZipData before opening (open_z.rs:230-241)."""
+    z = orc.Zip(8)
+    evals = _witness(8)
+    rows_o, layers_o, roots_o = z.commit(evals)
+    rows_m = rows_o.copy()
+    rows_m[5, 0] ^= np.uint64(1)
+    ctx = _ctx(cabi, z)
+    com = ctx.upload_commitment(rows_m, layers_o[:, :-1, :], roots_o)
+    cols = np.array([5, 6], dtype=np.uint32)
+    wire = com.open_columns(cols)
+    per_col = z.num_rows * (32 + 8 + 32 * z.depth)
+    assert wire[:32].tobytes() == rows_m[5].astype("<u8").tobytes()
+    assert wire[per_col:per_col + 32].tobytes() == rows_o[6].astype("<u8").tobytes()
+    r, l, t = com.download()
+    assert np.array_equal(r, rows_m) and np.array_equal(l, layers_o[:, :-1, :]) and np.array_equal(t, roots_o)
+
+
+def test_row_sharded_commit_and_open_match_unsharded(cabi):
+    """rows shard across GPUs; partial row combinations add exactly."""
+    torch = pytest.importorskip("torch")
+    nv, G = 10, 4
+    z = orc.Zip(nv)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    evals = _witness(nv)
+    rows_o, layers_o, roots_o = z.commit(evals)
+    coeffs = orc.splitmix64(5, z.num_rows)
+    q0 = orc.field_elems([int(x) * 0xDEADBEEFCAFEBABE1234567 % BENCH_MODULUS for x in orc.splitmix64(6, z.num_rows).view(np.uint64)], 4)
+    _, u_full = z.combine_rows_int(coeffs, evals)
+    row_full = z.combine_rows_field(f, q0, evals)
+    per = z.num_rows // G
+    uparts = torch.zeros((G, z.row_len, 8), dtype=torch.int64, device="cuda")
+    fparts = torch.zeros((G, z.row_len, 4), dtype=torch.int64, device="cuda")
+    cols = np.array([1, 7, 63], dtype=np.uint32)
+    ctxs = []
+    for g in range(G):
+        ctx = cabi.ZipContext(nv, z.perm1, z.perm2, row_begin=g * per, row_count=per)
+        ctxs.append(ctx)
+        sl = slice(g * per * z.row_len, (g + 1) * per * z.row_len)
+        com, roots = ctx.commit(evals[sl])
+        assert np.array_equal(roots, roots_o[g * per:(g + 1) * per])
+        ctx.open_testing(evals[sl], coeffs[g * per:(g + 1) * per], out=uparts[g])
+        ctx.open_eval(evals[sl], q0[g * per:(g + 1) * per], zf, out=fparts[g])
+        wire = com.open_columns(cols)
+        rows3 = rows_o.reshape(z.num_rows, z.codeword_len, 4)[g * per:(g + 1) * per]
+        assert wire[: per * 32].tobytes() == rows3[:, 1, :].astype("<u8").tobytes()
+        ctx.synchronize()
+    torch.cuda.synchronize()
+    u_out = torch.zeros((z.row_len, 8), dtype=torch.int64, device="cuda")
+    r_out = torch.zeros((z.row_len, 4), dtype=torch.int64, device="cuda")
+    ctxs[0].sum_partials(uparts, fparts, G, zf, u_out, r_out)
+    ctxs[0].synchronize()
+    assert np.array_equal(u_out.cpu().numpy().view(np.uint64), u_full)
+    assert np.array_equal(r_out.cpu().numpy().view(np.uint64), row_full)
+
+
+def test_standalone_merkle_trees(cabi):
+    """MerkleTree::new on random full-width leaves (benches/zip_benches.rs:80-98; pcs/utils.rs:340 uses Int<3>)."""
+    rng = np.random.default_rng(8)
+    for limbs, depth in ((4, 10), (3, 6), (1, 0), (8, 4)):
+        leaves = rng.integers(0, 2**64, size=(3, 1 << depth, limbs), dtype=np.uint64)
+        got = cabi.merkle_trees(leaves, depth)
+        for t in range(3):
+            assert np.array_equal(got[t], orc.merkle_tree(depth, leaves[t]))
+
+
+def test_profiling_hooks_report_kernels(cabi):
+    z = orc.Zip(10)
+    ctx = _ctx(cabi, z)
+    ctx.set_profiling(True)
+    ctx.commit(_witness(10))
+    times = ctx.profile_read()
+    assert "raa_commit_kernel" in times and times["raa_commit_kernel"][0] == 1
+    assert times["raa_commit_kernel"][1] > 0

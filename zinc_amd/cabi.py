@@ -1,0 +1,337 @@
+"""ctypes binding of libzip_hip.so (include/zip_hip.h).
+
+Thin by design: the product is the HIP library behind the C ABI; this module only
+marshals numpy arrays (host memory) and raw device pointers (e.g. torch tensors'
+``data_ptr()``) across it.  There is NO CPU fallback: if the shared library is
+missing or no gfx950 device is present the calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libzip_hip.so")
+
+ZIP_OK = 0
+ZIP_ERR_INVALID_PARAM = -1
+ZIP_ERR_SHAPE = -2
+ZIP_ERR_HIP = -3
+ZIP_ERR_NO_DEVICE = -4
+ZIP_ERR_UNSUPPORTED = -5
+ZIP_ERR_ALLOC = -6
+ZIP_ERR_NULL = -7
+MEM_HOST, MEM_DEVICE = 0, 1
+
+EXPORTED_SYMBOLS = (
+    "zip_abi_version", "zip_strerror", "zip_device_count", "zip_ctx_create", "zip_ctx_destroy",
+    "zip_ctx_last_error", "zip_ctx_synchronize", "zip_ctx_stream", "zip_commit", "zip_commitment_free",
+    "zip_commitment_device_ptrs", "zip_commit_download", "zip_commitment_upload", "zip_open_testing",
+    "zip_open_columns", "zip_open_eval", "zip_proof_len", "zip_open", "zip_sum_partials", "zip_merkle_trees",
+    "zip_ctx_set_profiling", "zip_ctx_profile_read",
+)
+
+
+class ZipError(RuntimeError):
+    def __init__(self, code, what, detail=""):
+        self.code = code
+        super().__init__(f"{what}: {strerror(code)} ({code})" + (f": {detail}" if detail else ""))
+
+
+class ZipParams(C.Structure):
+    _fields_ = [
+        ("num_vars", C.c_uint32), ("row_len", C.c_uint32), ("num_rows", C.c_uint32),
+        ("codeword_len", C.c_uint32), ("rep", C.c_uint32),
+        ("n_limbs", C.c_uint32), ("k_limbs", C.c_uint32), ("m_limbs", C.c_uint32),
+        ("perm1", C.POINTER(C.c_uint32)), ("perm2", C.POINTER(C.c_uint32)),
+        ("device", C.c_int32), ("row_begin", C.c_uint32), ("row_count", C.c_uint32),
+    ]
+
+
+class ZipField(C.Structure):
+    _fields_ = [("limbs", C.c_uint32), ("modulus", C.c_uint64 * 8)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("launches", C.c_uint32), ("total_ms", C.c_float)]
+
+
+_lib = None
+
+
+def lib():
+    """Loads the HIP library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m zinc_amd.build` "
+            "(__graft_entry__.build()).  The Zip HIP path has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u8p, u32p, u64p, i64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+    L.zip_abi_version.restype = C.c_int32
+    L.zip_strerror.restype = C.c_char_p
+    L.zip_strerror.argtypes = [C.c_int32]
+    L.zip_device_count.restype = C.c_int32
+    L.zip_ctx_create.argtypes = [C.POINTER(ZipParams), C.POINTER(vp)]
+    L.zip_ctx_destroy.argtypes = [vp]
+    L.zip_ctx_destroy.restype = None
+    L.zip_ctx_last_error.argtypes = [vp]
+    L.zip_ctx_last_error.restype = C.c_char_p
+    L.zip_ctx_synchronize.argtypes = [vp]
+    L.zip_ctx_stream.argtypes = [vp]
+    L.zip_ctx_stream.restype = vp
+    L.zip_commit.argtypes = [vp, i64p, C.c_size_t, C.c_int, C.c_int32, u8p, C.POINTER(vp)]
+    L.zip_commitment_free.argtypes = [vp]
+    L.zip_commitment_free.restype = None
+    L.zip_commitment_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.zip_commit_download.argtypes = [vp, u64p, u8p, u8p]
+    L.zip_commitment_upload.argtypes = [vp, u64p, u8p, u8p, C.POINTER(vp)]
+    L.zip_open_testing.argtypes = [vp, i64p, C.c_int, i64p, u64p, C.c_int]
+    L.zip_open_columns.argtypes = [vp, u32p, C.c_uint32, u8p, C.c_int]
+    L.zip_open_eval.argtypes = [vp, i64p, C.c_int, u64p, C.POINTER(ZipField), u64p, C.c_int]
+    L.zip_proof_len.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.zip_proof_len.restype = C.c_size_t
+    L.zip_open.argtypes = [vp, i64p, C.c_int, i64p, u32p, C.c_uint32, u64p, C.POINTER(ZipField), u8p, C.c_int]
+    L.zip_sum_partials.argtypes = [vp, u64p, u64p, C.c_uint32, C.POINTER(ZipField), u64p, u64p]
+    L.zip_merkle_trees.argtypes = [C.c_int32, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u8p]
+    L.zip_ctx_set_profiling.argtypes = [vp, C.c_int32]
+    L.zip_ctx_profile_read.argtypes = [vp, C.POINTER(KernelTime), C.c_uint32]
+    for fn in ("zip_ctx_create", "zip_ctx_synchronize", "zip_commit", "zip_commitment_device_ptrs",
+               "zip_commit_download", "zip_commitment_upload", "zip_open_testing", "zip_open_columns",
+               "zip_open_eval", "zip_open", "zip_sum_partials", "zip_merkle_trees", "zip_ctx_set_profiling",
+               "zip_ctx_profile_read"):
+        getattr(L, fn).restype = C.c_int32
+    _lib = L
+    return L
+
+
+def strerror(code):
+    return lib().zip_strerror(code).decode()
+
+
+def device_count():
+    return lib().zip_device_count()
+
+
+def make_field(modulus: int, limbs: int) -> ZipField:
+    f = ZipField()
+    f.limbs = limbs
+    for i in range(8):
+        f.modulus[i] = (modulus >> (64 * i)) & 0xFFFFFFFFFFFFFFFF if i < limbs else 0
+    return f
+
+
+def _ptr(x):
+    """(address, mem_kind) of a numpy array (host), a torch tensor, or None."""
+    if x is None:
+        return None, MEM_HOST
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"]
+        return x.ctypes.data, MEM_HOST
+    if hasattr(x, "data_ptr"):  # torch tensor
+        assert x.is_contiguous()
+        return x.data_ptr(), (MEM_DEVICE if x.is_cuda else MEM_HOST)
+    raise TypeError(type(x))
+
+
+def geometry(num_vars, rep=2):
+    """RaaCode::new + MultilinearZip::setup geometry (code_raa.rs:43,113; structs.rs:82)."""
+    n = 1 << num_vars
+    isqrt = int(np.floor(np.sqrt(n)))
+    while isqrt * isqrt > n:
+        isqrt -= 1
+    while (isqrt + 1) * (isqrt + 1) <= n:
+        isqrt += 1
+    row_len = 1
+    while row_len < isqrt:
+        row_len <<= 1
+    num_rows = 1
+    while num_rows < n // row_len:
+        num_rows <<= 1
+    return row_len, num_rows, row_len * rep
+
+
+class ZipContext:
+    """One geometry on one GPU (zip_ctx).  perm1/perm2: uint32 permutation tables."""
+
+    def __init__(self, num_vars, perm1, perm2, device=0, rep=2, row_begin=0, row_count=0,
+                 n_limbs=1, k_limbs=4, m_limbs=8, geometry_override=None):
+        L = lib()
+        row_len, num_rows, cw = geometry_override or geometry(num_vars, rep)
+        self.num_vars, self.row_len, self.num_rows, self.codeword_len, self.rep = num_vars, row_len, num_rows, cw, rep
+        self.depth = max(cw - 1, 0).bit_length() if cw > 1 else 0
+        self.rows_local = row_count or num_rows
+        self.row_begin = row_begin
+        self.k_limbs, self.m_limbs = k_limbs, m_limbs
+        self._perm1 = np.ascontiguousarray(perm1, dtype=np.uint32)
+        self._perm2 = np.ascontiguousarray(perm2, dtype=np.uint32)
+        p = ZipParams(num_vars, row_len, num_rows, cw, rep, n_limbs, k_limbs, m_limbs,
+                      self._perm1.ctypes.data_as(C.POINTER(C.c_uint32)),
+                      self._perm2.ctypes.data_as(C.POINTER(C.c_uint32)), device, row_begin, row_count)
+        h = C.c_void_p()
+        rc = L.zip_ctx_create(C.byref(p), C.byref(h))
+        if rc != ZIP_OK:
+            raise ZipError(rc, "zip_ctx_create")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().zip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != ZIP_OK:
+            raise ZipError(rc, what, lib().zip_ctx_last_error(self._h).decode())
+
+    def synchronize(self):
+        self._check(lib().zip_ctx_synchronize(self._h), "zip_ctx_synchronize")
+
+    @property
+    def stream(self):
+        return lib().zip_ctx_stream(self._h)
+
+    def commit(self, evals, with_merkle=True, want_roots=True):
+        """MultilinearZip::commit / commit_no_merkle.  evals: int64 numpy array or CUDA tensor."""
+        ptr, kind = _ptr(evals)
+        n = evals.size if isinstance(evals, np.ndarray) else evals.numel()
+        roots = np.zeros((self.rows_local, 32), dtype=np.uint8) if (with_merkle and want_roots) else None
+        h = C.c_void_p()
+        rc = lib().zip_commit(self._h, ptr, n, kind, int(with_merkle), roots.ctypes.data if roots is not None else None,
+                              C.byref(h))
+        self._check(rc, "zip_commit")
+        return Commitment(self, h, bool(with_merkle)), roots
+
+    def upload_commitment(self, rows, layers=None, roots=None):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        h = C.c_void_p()
+        rc = lib().zip_commitment_upload(
+            self._h, rows.ctypes.data,
+            None if layers is None else np.ascontiguousarray(layers, dtype=np.uint8).ctypes.data,
+            None if roots is None else np.ascontiguousarray(roots, dtype=np.uint8).ctypes.data, C.byref(h))
+        self._check(rc, "zip_commitment_upload")
+        return Commitment(self, h, layers is not None)
+
+    def open_testing(self, evals, coeffs, out=None):
+        ptr, kind = _ptr(evals)
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.int64)
+        assert coeffs.size == self.rows_local
+        res = out if out is not None else np.zeros((self.row_len, self.m_limbs), dtype=np.uint64)
+        optr, okind = _ptr(res)
+        self._check(lib().zip_open_testing(self._h, ptr, kind, coeffs.ctypes.data, optr, okind), "zip_open_testing")
+        return res
+
+    def open_eval(self, evals, q0_mont, field: ZipField, out=None):
+        ptr, kind = _ptr(evals)
+        q0p = None
+        if q0_mont is not None:
+            q0_mont = np.ascontiguousarray(q0_mont, dtype=np.uint64)
+            assert q0_mont.size == self.rows_local * field.limbs
+            q0p = q0_mont.ctypes.data
+        res = out if out is not None else np.zeros((self.row_len, field.limbs), dtype=np.uint64)
+        optr, okind = _ptr(res)
+        self._check(lib().zip_open_eval(self._h, ptr, kind, q0p, C.byref(field), optr, okind), "zip_open_eval")
+        return res
+
+    def proof_len(self, n_cols, field_limbs):
+        return lib().zip_proof_len(self._h, n_cols, field_limbs)
+
+    def sum_partials(self, uparts, fparts, n_parts, field, uprime_out, row_out):
+        up = _ptr(uparts)[0] if uparts is not None else None
+        fp = _ptr(fparts)[0] if fparts is not None else None
+        uo = _ptr(uprime_out)[0] if uprime_out is not None else None
+        ro = _ptr(row_out)[0] if row_out is not None else None
+        self._check(lib().zip_sum_partials(self._h, up, fp, n_parts, C.byref(field) if field is not None else None,
+                                           uo, ro), "zip_sum_partials")
+
+    def set_profiling(self, on=True):
+        self._check(lib().zip_ctx_set_profiling(self._h, int(on)), "zip_ctx_set_profiling")
+
+    def profile_read(self):
+        buf = (KernelTime * 32)()
+        n = lib().zip_ctx_profile_read(self._h, buf, 32)
+        if n < 0:
+            self._check(n, "zip_ctx_profile_read")
+        return {buf[i].name.decode(): (buf[i].launches, buf[i].total_ms) for i in range(min(n, 32))}
+
+
+class Commitment:
+    """Device-resident MultilinearZipData (+ roots) behind a zip_commitment handle."""
+
+    def __init__(self, ctx: ZipContext, handle, has_merkle):
+        self.ctx, self._h, self.has_merkle = ctx, handle, has_merkle
+
+    def free(self):
+        if getattr(self, "_h", None) and self.ctx._h:
+            lib().zip_commitment_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def device_ptrs(self):
+        r, l, t = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self.ctx._check(lib().zip_commitment_device_ptrs(self._h, C.byref(r), C.byref(l), C.byref(t)),
+                        "zip_commitment_device_ptrs")
+        return r.value, l.value, t.value
+
+    def download(self, rows=True, layers=True, roots=True):
+        c = self.ctx
+        R, cw = c.rows_local, c.codeword_len
+        rows_a = np.zeros((R * cw, c.k_limbs), dtype=np.uint64) if rows else None
+        layers_a = np.zeros((R, 2 * cw - 2, 32), dtype=np.uint8) if (layers and self.has_merkle) else None
+        roots_a = np.zeros((R, 32), dtype=np.uint8) if (roots and self.has_merkle) else None
+        rc = lib().zip_commit_download(self._h, rows_a.ctypes.data if rows_a is not None else None,
+                                       layers_a.ctypes.data if layers_a is not None else None,
+                                       roots_a.ctypes.data if roots_a is not None else None)
+        c._check(rc, "zip_commit_download")
+        return rows_a, layers_a, roots_a
+
+    def open_columns(self, cols, out=None):
+        c = self.ctx
+        cols = np.ascontiguousarray(cols, dtype=np.uint32)
+        nbytes = cols.size * c.rows_local * (8 * c.k_limbs + 8 + 32 * c.depth)
+        res = out if out is not None else np.zeros(nbytes, dtype=np.uint8)
+        optr, okind = _ptr(res)
+        c._check(lib().zip_open_columns(self._h, cols.ctypes.data, cols.size, optr, okind), "zip_open_columns")
+        return res
+
+    def open(self, evals, coeffs, cols, q0_mont, field: ZipField, out=None):
+        """Whole proof stream of MultilinearZip::open (the field elements still need absorbing)."""
+        c = self.ctx
+        ptr, kind = _ptr(evals)
+        cols = np.ascontiguousarray(cols, dtype=np.uint32)
+        cp = np.ascontiguousarray(coeffs, dtype=np.int64).ctypes.data if coeffs is not None else None
+        q0 = np.ascontiguousarray(q0_mont, dtype=np.uint64) if q0_mont is not None else None
+        total = c.proof_len(cols.size, field.limbs)
+        res = out if out is not None else np.zeros(total, dtype=np.uint8)
+        optr, okind = _ptr(res)
+        rc = lib().zip_open(self._h, ptr, kind, cp, cols.ctypes.data, cols.size,
+                            q0.ctypes.data if q0 is not None else None, C.byref(field), optr, okind)
+        c._check(rc, "zip_open")
+        return res
+
+
+def merkle_trees(leaves, depth, device=0):
+    """MerkleTree::new over [num_trees, 2^depth, limbs] uint64 leaves; returns [num_trees, (2<<depth)-1, 32]."""
+    leaves = np.ascontiguousarray(leaves, dtype=np.uint64)
+    if leaves.ndim == 2:
+        leaves = leaves[None]
+    num_trees, n, limbs = leaves.shape
+    assert n == 1 << depth
+    out = np.zeros((num_trees, (2 << depth) - 1, 32), dtype=np.uint8)
+    rc = lib().zip_merkle_trees(device, leaves.ctypes.data, limbs, depth, num_trees, MEM_HOST, out.ctypes.data)
+    if rc != ZIP_OK:
+        raise ZipError(rc, "zip_merkle_trees")
+    return out

@@ -1,0 +1,350 @@
+// Open-side kernels: the two row combinations (proximity test over Z, evaluation
+// phase over F_q) fused into one pass over the witness, and the column-opening
+// gather that emits the reference's proof-stream wire format.
+//
+// Reference loops replaced:
+//   combine_rows over Int<M>           src/zip/utils.rs:94-127 via src/zip/pcs/open_z.rs:103-112
+//   map_to_field + combine_rows over F src/zip/pcs/open_z.rs:76-90, src/conversion.rs:86-100,
+//                                      src/field.rs:536-568, src/field/config.rs:163-170
+//   open_merkle_trees_for_column       src/zip/pcs/open_z.rs:124-143, src/zip/pcs/utils.rs:163-176,220-233,
+//                                      src/zip/pcs_transcript.rs:115-135,198-211
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zipk {
+
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+// ---------------------------------------------------------------------------
+// multi-limb helpers (little-endian uint64 limbs)
+// ---------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ uint64_t add_n(uint64_t (&a)[N], const uint64_t (&b)[N]) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const u128 t = (u128)a[i] + b[i] + carry;
+        a[i] = (uint64_t)t;
+        carry = (uint64_t)(t >> 64);
+    }
+    return carry;
+}
+template <int N>
+__device__ __forceinline__ uint64_t sub_n(uint64_t (&a)[N], const uint64_t (&b)[N]) {
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const u128 t = (u128)a[i] - b[i] - borrow;
+        a[i] = (uint64_t)t;
+        borrow = (uint64_t)(t >> 64) & 1;
+    }
+    return borrow;
+}
+template <int N>
+__device__ __forceinline__ bool geq_n(const uint64_t (&a)[N], const uint64_t (&b)[N]) {
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) {
+        if (a[i] != b[i]) return a[i] > b[i];
+    }
+    return true;
+}
+
+template <int FL>
+struct FieldDev {
+    uint64_t modulus[FL];
+    uint64_t r2[FL];
+    uint64_t inv;
+};
+
+// Montgomery reduction of a 2*FL-limb value t < q*R: returns t * R^-1 mod q, canonical.
+// Same arithmetic as src/field/biginteger.rs:532-560 + the conditional subtraction of
+// src/field/config.rs:68-76 (carry branch for moduli without a spare bit).
+template <int FL>
+__device__ __forceinline__ void mont_redc(uint64_t (&t)[2 * FL], const FieldDev<FL> &f, uint64_t (&out)[FL]) {
+    uint64_t carry2 = 0;
+#pragma unroll
+    for (int i = 0; i < FL; i++) {
+        const uint64_t k = t[i] * f.inv;
+        uint64_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < FL; j++) {
+            const u128 x = (u128)k * f.modulus[j] + t[i + j] + carry;
+            t[i + j] = (uint64_t)x;
+            carry = (uint64_t)(x >> 64);
+        }
+        const u128 y = (u128)t[i + FL] + carry + carry2;
+        t[i + FL] = (uint64_t)y;
+        carry2 = (uint64_t)(y >> 64);
+    }
+#pragma unroll
+    for (int i = 0; i < FL; i++) out[i] = t[FL + i];
+    if (carry2 || geq_n<FL>(out, f.modulus)) sub_n<FL>(out, f.modulus);
+}
+
+template <int FL>
+__device__ __forceinline__ void mont_mul(const uint64_t (&a)[FL], const uint64_t (&b)[FL], const FieldDev<FL> &f,
+                                         uint64_t (&out)[FL]) {
+    uint64_t t[2 * FL];
+#pragma unroll
+    for (int i = 0; i < 2 * FL; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < FL; i++) {
+        uint64_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < FL; j++) {
+            const u128 x = (u128)a[i] * b[j] + t[i + j] + carry;
+            t[i + j] = (uint64_t)x;
+            carry = (uint64_t)(x >> 64);
+        }
+        t[i + FL] = carry;
+    }
+    mont_redc<FL>(t, f, out);
+}
+
+// y (FL+2 limbs, < q * 2^(64+16)) mod q, canonical:  REDC(y) * R^2 * R^-1.
+template <int FL>
+__device__ __forceinline__ void reduce_wide(const uint64_t (&y)[FL + 2], const FieldDev<FL> &f, uint64_t (&out)[FL]) {
+    uint64_t t[2 * FL];
+#pragma unroll
+    for (int i = 0; i < 2 * FL; i++) t[i] = (i < FL + 2) ? y[i] : 0;
+    uint64_t z[FL];
+    mont_redc<FL>(t, f, z);
+    mont_mul<FL>(z, f.r2, f, out);
+}
+
+// ---------------------------------------------------------------------------
+// Fused row combinations.  One thread per witness column, blockIdx.y selects a
+// chunk of rows; exact partial sums go to HBM and are folded by
+// combine_finalize_kernel.
+//   over Z :  u'[c]  = sum_r coeff[r] * w[r][c]        192-bit accumulator (|.| < 2^(126+16))
+//   over Fq:  row[c] = sum_r q0_mont[r] * w[r][c] mod q  == the reference's
+//             sum_r q0[r] (x) phi(w[r][c]) because phi(w) = w*R mod q and every
+//             reference operation returns the canonical residue.  w (signed) is
+//             split as (u64)w - 2^64*[w<0]:  A = sum q0*(u64)w,  B = sum_{w<0} q0.
+// quirk_mod != 0 reproduces the reference's `%=` against a modulus read as a
+// negative Int (see oracle/zip_oracle.c field_from_signed_words): |w| is first
+// reduced modulo quirk_mod = 2^(64*FL) - q when that is < 2^64.
+// ---------------------------------------------------------------------------
+struct CombineArgs {
+    const int64_t *evals;   // [num_rows][row_len]
+    const int64_t *coeffs;  // [num_rows]            (device)
+    const uint64_t *q0;     // [num_rows][FL]        (device, Montgomery limbs)
+    uint32_t num_rows, row_len, rows_per_chunk;
+    uint64_t quirk_mod;
+    uint64_t *part_int;  // [chunks][row_len][3]
+    uint64_t *part_a;    // [chunks][row_len][FL+2]
+    uint64_t *part_b;    // [chunks][row_len][FL+1]
+};
+
+template <int FL, bool DO_INT, bool DO_FIELD>
+__global__ void __launch_bounds__(256) combine_rows_kernel(CombineArgs a) {
+    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= a.row_len) return;
+    const uint32_t chunk = blockIdx.y;
+    const uint32_t r0 = chunk * a.rows_per_chunk;
+    const uint32_t r1 = min(r0 + a.rows_per_chunk, a.num_rows);
+
+    uint64_t ai[3] = {0, 0, 0};
+    uint64_t A[FL + 2], B[FL + 1];
+#pragma unroll
+    for (int i = 0; i < FL + 2; i++) A[i] = 0;
+#pragma unroll
+    for (int i = 0; i < FL + 1; i++) B[i] = 0;
+
+    const int64_t *p = a.evals + (size_t)r0 * a.row_len + col;
+#pragma unroll 4
+    for (uint32_t r = r0; r < r1; r++, p += a.row_len) {
+        int64_t w = *p;
+        if (DO_INT) {
+            const i128 prod = (i128)a.coeffs[r] * (i128)w;
+            const u128 lo = ((u128)ai[1] << 64 | ai[0]) + (u128)prod;
+            const uint64_t carry = lo < (u128)prod ? 1 : 0;
+            ai[0] = (uint64_t)lo;
+            ai[1] = (uint64_t)(lo >> 64);
+            ai[2] += (uint64_t)(int64_t)(prod >> 127) + carry;  // sign extension word + carry
+        }
+        if (DO_FIELD) {
+            if (a.quirk_mod) {
+                const uint64_t mag = (w < 0 ? (uint64_t)0 - (uint64_t)w : (uint64_t)w) % a.quirk_mod;
+                w = (w < 0) ? -(int64_t)mag : (int64_t)mag;
+            }
+            const uint64_t wu = (uint64_t)w;
+            const uint64_t *q = a.q0 + (size_t)r * FL;  // wave-uniform -> scalar loads
+            uint64_t carry = 0;
+#pragma unroll
+            for (int i = 0; i < FL; i++) {
+                const u128 x = (u128)q[i] * wu + A[i] + carry;
+                A[i] = (uint64_t)x;
+                carry = (uint64_t)(x >> 64);
+            }
+            const u128 y = (u128)A[FL] + carry;
+            A[FL] = (uint64_t)y;
+            A[FL + 1] += (uint64_t)(y >> 64);
+            const uint64_t mask = (w < 0) ? ~(uint64_t)0 : 0;
+            carry = 0;
+#pragma unroll
+            for (int i = 0; i < FL; i++) {
+                const u128 x = (u128)B[i] + (q[i] & mask) + carry;
+                B[i] = (uint64_t)x;
+                carry = (uint64_t)(x >> 64);
+            }
+            B[FL] += carry;
+        }
+    }
+    const size_t slot = (size_t)chunk * a.row_len + col;
+    if (DO_INT) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) a.part_int[slot * 3 + i] = ai[i];
+    }
+    if (DO_FIELD) {
+#pragma unroll
+        for (int i = 0; i < FL + 2; i++) a.part_a[slot * (FL + 2) + i] = A[i];
+#pragma unroll
+        for (int i = 0; i < FL + 1; i++) a.part_b[slot * (FL + 1) + i] = B[i];
+    }
+}
+
+struct FinalizeArgs {
+    const uint64_t *part_int, *part_a, *part_b;
+    uint32_t chunks, row_len, m_limbs;
+    uint64_t *uprime;     // [row_len][m_limbs] little-endian limbs, or null
+    uint64_t *row_limbs;  // [row_len][FL] Montgomery little-endian limbs, or null
+    uint8_t *row_be;      // [row_len][8*FL] big-endian bytes of the Montgomery value, or null
+};
+
+template <int FL, bool DO_INT, bool DO_FIELD>
+__global__ void __launch_bounds__(256) combine_finalize_kernel(FinalizeArgs a, FieldDev<FL> f) {
+    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= a.row_len) return;
+    if (DO_INT) {
+        uint64_t s[3] = {0, 0, 0};
+        for (uint32_t c = 0; c < a.chunks; c++) {
+            uint64_t t[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) t[i] = a.part_int[((size_t)c * a.row_len + col) * 3 + i];
+            add_n<3>(s, t);
+        }
+        const uint64_t sign = (uint64_t)((int64_t)s[2] >> 63);
+        if (a.uprime) {
+            for (uint32_t i = 0; i < a.m_limbs; i++)  // write_integer: limbs little-endian, pcs_transcript.rs:115-123
+                a.uprime[(size_t)col * a.m_limbs + i] = i < 3 ? s[i] : sign;
+        }
+    }
+    if (DO_FIELD) {
+        uint64_t A[FL + 2], Bs[FL + 2];
+#pragma unroll
+        for (int i = 0; i < FL + 2; i++) { A[i] = 0; Bs[i] = 0; }
+        for (uint32_t c = 0; c < a.chunks; c++) {
+            const size_t slot = (size_t)c * a.row_len + col;
+            uint64_t t[FL + 2], u[FL + 2];
+#pragma unroll
+            for (int i = 0; i < FL + 2; i++) t[i] = a.part_a[slot * (FL + 2) + i];
+            u[0] = 0;  // B * 2^64
+#pragma unroll
+            for (int i = 0; i < FL + 1; i++) u[i + 1] = a.part_b[slot * (FL + 1) + i];
+            add_n<FL + 2>(A, t);
+            add_n<FL + 2>(Bs, u);
+        }
+        uint64_t ra[FL], rb[FL];
+        reduce_wide<FL>(A, f, ra);
+        reduce_wide<FL>(Bs, f, rb);
+        if (!geq_n<FL>(ra, rb)) add_n<FL>(ra, f.modulus);  // wraps mod 2^(64 FL) when q has no spare bit; fine
+        sub_n<FL>(ra, rb);
+        if (a.row_limbs) {
+#pragma unroll
+            for (int i = 0; i < FL; i++) a.row_limbs[(size_t)col * FL + i] = ra[i];
+        }
+        if (a.row_be) {  // BigInt::to_bytes_be of the Montgomery value, pcs_transcript.rs:107-113
+            uint64_t *dst = reinterpret_cast<uint64_t *>(a.row_be + (size_t)col * 8 * FL);
+#pragma unroll
+            for (int i = 0; i < FL; i++) dst[i] = __builtin_bswap64(ra[FL - 1 - i]);
+        }
+    }
+}
+
+// Sum of G partial results of a row-sharded open (one per GPU after the RCCL
+// all-gather): exact 512-bit adds for u', modular adds for the evaluation row.
+template <int FL>
+__global__ void __launch_bounds__(256) sum_partials_kernel(const uint64_t *uparts, const uint64_t *fparts,
+                                                           uint32_t G, uint32_t row_len, uint32_t m_limbs,
+                                                           uint64_t *uprime, uint64_t *row_limbs, FieldDev<FL> f) {
+    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= row_len) return;
+    if (uparts) {
+        uint64_t carry = 0;
+        for (uint32_t i = 0; i < m_limbs; i++) {
+            u128 acc = carry;
+            for (uint32_t g = 0; g < G; g++) acc += uparts[((size_t)g * row_len + col) * m_limbs + i];
+            uprime[(size_t)col * m_limbs + i] = (uint64_t)acc;
+            carry = (uint64_t)(acc >> 64);
+        }
+    }
+    if (fparts) {
+        uint64_t acc[FL];
+#pragma unroll
+        for (int i = 0; i < FL; i++) acc[i] = 0;
+        for (uint32_t g = 0; g < G; g++) {
+            uint64_t t[FL];
+#pragma unroll
+            for (int i = 0; i < FL; i++) t[i] = fparts[((size_t)g * row_len + col) * FL + i];
+            const uint64_t c = add_n<FL>(acc, t);
+            if (c || geq_n<FL>(acc, f.modulus)) sub_n<FL>(acc, f.modulus);
+        }
+#pragma unroll
+        for (int i = 0; i < FL; i++) row_limbs[(size_t)col * FL + i] = acc[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Column openings in wire format.  For opened column i (index cols[i]):
+//   num_rows x K limbs little-endian            rows[r*cw + col]            (open_z.rs:130-137)
+//   num_rows x { be64(depth), depth x 32 B }    sibling (col >> k) ^ 1 of level k, leaf level first
+//                                               (pcs/utils.rs:163-176, pcs_transcript.rs:198-211)
+// Grid: (n_cols, row chunks).  Everything is moved as 8-byte words because a
+// path record (8 + 32*depth bytes) is only 8-byte aligned in the stream.
+// ---------------------------------------------------------------------------
+struct OpenColsArgs {
+    const uint64_t *rows;    // [num_rows][cw][K]
+    const uint64_t *layers;  // [num_rows][2*cw][4]
+    const uint32_t *cols;    // [n_cols] (device)
+    uint8_t *out;            // wire stream of the openings
+    uint32_t num_rows, cw, depth, k_limbs, rows_per_block;
+};
+
+__global__ void __launch_bounds__(256) open_columns_kernel(OpenColsArgs a) {
+    const uint32_t ci = blockIdx.x;
+    const uint32_t col = a.cols[ci];
+    const uint32_t r0 = blockIdx.y * a.rows_per_block;
+    const uint32_t r1 = min(r0 + a.rows_per_block, a.num_rows);
+    const uint32_t K = a.k_limbs, d = a.depth;
+    const uint32_t rec_words = 1 + 4 * d;
+    const size_t col_bytes = (size_t)a.num_rows * (8 * K + 8 * rec_words);
+    uint64_t *vals = reinterpret_cast<uint64_t *>(a.out + (size_t)ci * col_bytes);
+    uint64_t *recs = vals + (size_t)a.num_rows * K;
+
+    // column values: K words per row
+    for (uint32_t i = threadIdx.x; i < (r1 - r0) * K; i += blockDim.x) {
+        const uint32_t r = r0 + i / K, k = i % K;
+        vals[(size_t)r * K + k] = a.rows[((size_t)r * a.cw + col) * K + k];
+    }
+    // Merkle paths: one 64-lane wave per row record (rec_words <= 64 for depth <= 15)
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (uint32_t r = r0 + wid; r < r1; r += nw) {
+        const uint64_t *tree = a.layers + (size_t)r * (2u * a.cw) * 4;
+        for (uint32_t k = lane; k < rec_words; k += 64) {
+            uint64_t word;
+            if (k == 0) {
+                word = __builtin_bswap64((uint64_t)d);
+            } else {
+                const uint32_t lvl = (k - 1) >> 2, part = (k - 1) & 3;
+                const uint32_t off = 2u * a.cw - ((2u * a.cw) >> lvl);
+                word = tree[((size_t)off + ((col >> lvl) ^ 1u)) * 4 + part];
+            }
+            recs[(size_t)r * rec_words + k] = word;
+        }
+    }
+}
+
+}  // namespace zipk

@@ -1,0 +1,976 @@
+// libzip_hip.so -- C ABI (include/zip_hip.h) over the gfx950 kernels.
+// Host-side runtime: context / stream ownership, a caching device allocator (so a
+// commit of several GiB does not pay hipMalloc/hipFree per call), geometry
+// validation mirroring the reference's error behaviour, kernel dispatch and the
+// HIP-event measurement hooks used by bench.py.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/zip_hip.h"
+#include "kernels_commit.cuh"
+#include "kernels_open.cuh"
+
+using namespace zipk;
+
+namespace {
+
+typedef unsigned __int128 u128;
+
+// ------------------------------------------------------------------ small utils
+bool is_pow2(uint64_t x) { return x && !(x & (x - 1)); }
+uint32_t ilog2(uint64_t x) { return 63u - (uint32_t)__builtin_clzll(x); }
+
+struct KernelStat {
+    uint32_t launches = 0;
+    float total_ms = 0.f;
+};
+struct PendingEvent {
+    const char *name;
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct zip_ctx {
+    zip_params p{};
+    uint32_t depth = 0;
+    uint32_t rows_local = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t *perm1_d = nullptr, *perm2_d = nullptr;
+    std::string last_error;
+    // caching allocator: exact-size free lists
+    std::multimap<size_t, void *> free_blocks;
+    std::map<void *, size_t> live_blocks;
+    std::mutex mu;
+    // measurement
+    bool profiling = false;
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+    std::map<std::string, KernelStat> stats;
+    std::vector<std::string> stat_names;  // stable storage for returned names
+};
+
+struct zip_commitment {
+    zip_ctx *ctx = nullptr;
+    uint64_t *rows = nullptr;   // [rows_local][cw][4]
+    uint32_t *layers = nullptr;  // [rows_local][2cw][8] or null (commit_no_merkle)
+    uint32_t *roots = nullptr;   // [rows_local][8] or null
+    int64_t *evals = nullptr;    // device copy owned by the handle when the witness came from the host
+    size_t rows_bytes = 0, layers_bytes = 0, roots_bytes = 0, evals_bytes = 0;
+};
+
+namespace {
+
+int32_t fail(zip_ctx *ctx, int32_t code, const char *fmt, ...) {
+    if (ctx) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        ctx->last_error = buf;
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, ZIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+int32_t pool_alloc(zip_ctx *ctx, size_t bytes, void **out) {
+    *out = nullptr;
+    if (bytes == 0) bytes = 16;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    auto it = ctx->free_blocks.find(bytes);
+    if (it != ctx->free_blocks.end()) {
+        *out = it->second;
+        ctx->free_blocks.erase(it);
+    } else {
+        hipError_t e = hipMalloc(out, bytes);
+        if (e != hipSuccess) {
+            // release cached blocks and retry once
+            for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
+            ctx->free_blocks.clear();
+            e = hipMalloc(out, bytes);
+            if (e != hipSuccess)
+                return fail(ctx, ZIP_ERR_ALLOC, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        }
+    }
+    ctx->live_blocks[*out] = bytes;
+    return ZIP_OK;
+}
+
+void pool_release(zip_ctx *ctx, void *ptr) {
+    if (!ptr) return;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    auto it = ctx->live_blocks.find(ptr);
+    if (it == ctx->live_blocks.end()) return;
+    ctx->free_blocks.emplace(it->second, ptr);
+    ctx->live_blocks.erase(it);
+}
+
+// RAII for temporaries taken from the pool.  Stream order makes reuse safe: every
+// consumer of a block is enqueued on ctx->stream before the block can be handed out again.
+struct Scratch {
+    zip_ctx *ctx;
+    void *ptr = nullptr;
+    explicit Scratch(zip_ctx *c) : ctx(c) {}
+    ~Scratch() { pool_release(ctx, ptr); }
+    int32_t get(size_t bytes) { return pool_alloc(ctx, bytes, &ptr); }
+    template <class T>
+    T *as() { return static_cast<T *>(ptr); }
+};
+
+// ------------------------------------------------------------------ measurement
+hipEvent_t take_event(zip_ctx *ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct LaunchTimer {
+    zip_ctx *ctx;
+    PendingEvent pe{};
+    bool on;
+    LaunchTimer(zip_ctx *c, const char *name) : ctx(c), on(c->profiling) {
+        if (!on) return;
+        pe.name = name;
+        pe.start = take_event(ctx);
+        pe.stop = take_event(ctx);
+        (void)hipEventRecord(pe.start, ctx->stream);
+    }
+    ~LaunchTimer() {
+        if (!on) return;
+        (void)hipEventRecord(pe.stop, ctx->stream);
+        ctx->pending.push_back(pe);
+    }
+};
+
+// ------------------------------------------------------------------ field setup
+struct HostField {
+    uint32_t fl = 0;
+    uint64_t modulus[8]{}, r[8]{}, r2[8]{};
+    uint64_t inv = 0;
+    uint64_t quirk_mod = 0;
+};
+
+int cmp_limbs(const uint64_t *a, const uint64_t *b, uint32_t n) {
+    for (uint32_t i = n; i-- > 0;)
+        if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+    return 0;
+}
+void sub_limbs(uint64_t *a, const uint64_t *b, uint32_t n) {
+    uint64_t borrow = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        u128 d = (u128)a[i] - b[i] - borrow;
+        a[i] = (uint64_t)d;
+        borrow = (uint64_t)(d >> 64) & 1;
+    }
+}
+void dbl_mod(uint64_t *x, const uint64_t *q, uint32_t n) {
+    const uint64_t top = x[n - 1] >> 63;
+    for (uint32_t i = n; i-- > 1;) x[i] = (x[i] << 1) | (x[i - 1] >> 63);
+    x[0] <<= 1;
+    if (top || cmp_limbs(x, q, n) >= 0) sub_limbs(x, q, n);
+}
+
+// FieldConfig::new (src/field/config.rs:174-214): R, R^2 mod q and -q^-1 mod 2^64.
+int32_t make_field(zip_ctx *ctx, const zip_field *zf, HostField *f) {
+    if (!zf) return fail(ctx, ZIP_ERR_NULL, "field is NULL");
+    if (zf->limbs < 2 || zf->limbs > 4)
+        return fail(ctx, ZIP_ERR_UNSUPPORTED, "field limbs %u not in {2,3,4}", zf->limbs);
+    if (!(zf->modulus[0] & 1)) return fail(ctx, ZIP_ERR_INVALID_PARAM, "modulus must be odd");
+    const uint32_t n = f->fl = zf->limbs;
+    bool gt1 = zf->modulus[0] > 1;
+    for (uint32_t i = 1; i < n; i++) gt1 |= zf->modulus[i] != 0;
+    if (!gt1) return fail(ctx, ZIP_ERR_INVALID_PARAM, "modulus must be > 1");
+    memcpy(f->modulus, zf->modulus, 8 * n);
+    uint64_t inv = 1;
+    for (int i = 0; i < 63; i++) {
+        inv *= inv;
+        inv *= f->modulus[0];
+    }
+    f->inv = (uint64_t)0 - inv;
+    uint64_t x[8] = {1};
+    for (uint32_t i = 0; i < 64 * n; i++) dbl_mod(x, f->modulus, n);
+    memcpy(f->r, x, 8 * n);
+    for (uint32_t i = 0; i < 64 * n; i++) dbl_mod(x, f->modulus, n);
+    memcpy(f->r2, x, 8 * n);
+    // A modulus with its top bit set is a negative Int<FL> inside the reference's `%=`
+    // (src/field.rs:550-557, F::I = Int<N> at src/field.rs:280); observable for 64-bit
+    // witnesses only when 2^(64 FL) - q < 2^64.
+    f->quirk_mod = 0;
+    if (f->modulus[n - 1] >> 63) {
+        uint64_t m[8] = {0};
+        sub_limbs(m, f->modulus, n);  // 2^(64n) - q
+        bool small = true;
+        for (uint32_t i = 1; i < n; i++) small &= (m[i] == 0);
+        if (small) f->quirk_mod = m[0];
+    }
+    return ZIP_OK;
+}
+
+template <int FL>
+FieldDev<FL> to_dev(const HostField &h) {
+    FieldDev<FL> d;
+    for (int i = 0; i < FL; i++) {
+        d.modulus[i] = h.modulus[i];
+        d.r2[i] = h.r2[i];
+    }
+    d.inv = h.inv;
+    return d;
+}
+
+// ------------------------------------------------------------------ commit dispatch
+template <int E, bool HASH, bool T2_LDS>
+int32_t launch_commit(zip_ctx *ctx, const CommitArgs &a, uint32_t threads) {
+    const size_t lds = 256 + (T2_LDS ? (size_t)a.cw * 12 + (size_t)a.row_len * 8 : 0);
+    auto kern = raa_commit_kernel<E, HASH, T2_LDS>;
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    LaunchTimer t(ctx, HASH ? "raa_commit_kernel" : "raa_encode_kernel");
+    hipLaunchKernelGGL(kern, dim3(ctx->rows_local), dim3(threads), lds, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return ZIP_OK;
+}
+
+template <bool HASH>
+int32_t dispatch_commit(zip_ctx *ctx, CommitArgs a, uint32_t *levels_done) {
+    const uint32_t cw = a.cw;
+    if (cw == 16384) {
+        a.nact = cw / 16;
+        *levels_done = 4;
+        return launch_commit<16, HASH, false>(ctx, a, 1024);
+    }
+    if (cw >= 512) {
+        a.nact = cw / 8;
+        *levels_done = 3;
+        return launch_commit<8, HASH, true>(ctx, a, cw / 8);
+    }
+    if (cw == 256) {
+        a.nact = 64;
+        *levels_done = 2;
+        return launch_commit<4, HASH, true>(ctx, a, 64);
+    }
+    if (cw == 128) {
+        a.nact = 64;
+        *levels_done = 1;
+        return launch_commit<2, HASH, true>(ctx, a, 64);
+    }
+    a.nact = cw;  // cw <= 64: one entry per lane, upper lanes idle
+    *levels_done = 0;
+    return launch_commit<1, HASH, true>(ctx, a, 64);
+}
+
+template <int NL>
+int32_t launch_upper(zip_ctx *ctx, uint32_t *layers, uint32_t *roots, uint32_t trees, uint32_t cw,
+                     uint32_t level_in, uint32_t depth) {
+    const uint64_t total = (uint64_t)trees * ((cw >> level_in) >> NL);
+    const uint32_t threads = 256;
+    const uint32_t blocks = (uint32_t)((total + threads - 1) / threads);
+    LaunchTimer t(ctx, "merkle_upper_kernel");
+    hipLaunchKernelGGL(merkle_upper_kernel<NL>, dim3(blocks), dim3(threads), 0, ctx->stream, layers, roots,
+                       trees, cw, level_in, depth);
+    HIP_TRY(ctx, hipGetLastError());
+    return ZIP_OK;
+}
+
+int32_t merkle_upper_levels(zip_ctx *ctx, uint32_t *layers, uint32_t *roots, uint32_t trees, uint32_t cw,
+                            uint32_t level, uint32_t depth) {
+    if (depth == 0) {
+        LaunchTimer t(ctx, "copy_roots_depth0_kernel");
+        hipLaunchKernelGGL(copy_roots_depth0_kernel, dim3((trees + 255) / 256), dim3(256), 0, ctx->stream,
+                           layers, roots, trees, cw);
+        HIP_TRY(ctx, hipGetLastError());
+        return ZIP_OK;
+    }
+    while (level < depth) {
+        const uint32_t rem = depth - level;
+        int32_t rc;
+        if (rem >= 4) {
+            rc = launch_upper<4>(ctx, layers, roots, trees, cw, level, depth);
+            level += 4;
+        } else if (rem == 3) {
+            rc = launch_upper<3>(ctx, layers, roots, trees, cw, level, depth);
+            level += 3;
+        } else if (rem == 2) {
+            rc = launch_upper<2>(ctx, layers, roots, trees, cw, level, depth);
+            level += 2;
+        } else {
+            rc = launch_upper<1>(ctx, layers, roots, trees, cw, level, depth);
+            level += 1;
+        }
+        if (rc) return rc;
+    }
+    return ZIP_OK;
+}
+
+// Brings a witness shard onto the device if it is host memory.
+int32_t stage_evals(zip_ctx *ctx, const int64_t *evals, zip_mem_kind kind, size_t n, Scratch &tmp,
+                    const int64_t **dev) {
+    if (!evals) return fail(ctx, ZIP_ERR_NULL, "evals is NULL");
+    if (kind == ZIP_MEM_DEVICE) {
+        *dev = evals;
+        return ZIP_OK;
+    }
+    int32_t rc = tmp.get(n * 8);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(tmp.ptr, evals, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    *dev = tmp.as<int64_t>();
+    return ZIP_OK;
+}
+
+// ------------------------------------------------------------------ open pieces
+struct CombineOut {
+    uint64_t *uprime = nullptr;     // device
+    uint64_t *row_limbs = nullptr;  // device
+    uint8_t *row_be = nullptr;      // device
+};
+
+template <int FL>
+int32_t run_combine_fl(zip_ctx *ctx, const int64_t *evals_d, const int64_t *coeffs_h, const uint64_t *q0_h,
+                       const HostField *hf, bool do_int, bool do_field, const CombineOut &out) {
+    const uint32_t R = ctx->rows_local, C = ctx->p.row_len;
+    const uint32_t bx = (C + 255) / 256;
+    uint32_t chunks = 512 / bx;
+    if (chunks < 1) chunks = 1;
+    if (chunks > R) chunks = R;
+    const uint32_t rpc = (R + chunks - 1) / chunks;
+    chunks = (R + rpc - 1) / rpc;
+
+    Scratch coeffs_d(ctx), q0_d(ctx), pint(ctx), pa(ctx), pb(ctx);
+    int32_t rc;
+    CombineArgs a{};
+    a.evals = evals_d;
+    a.num_rows = R;
+    a.row_len = C;
+    a.rows_per_chunk = rpc;
+    a.quirk_mod = hf ? hf->quirk_mod : 0;
+    if (do_int) {
+        if ((rc = coeffs_d.get((size_t)R * 8))) return rc;
+        if ((rc = pint.get((size_t)chunks * C * 3 * 8))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(coeffs_d.ptr, coeffs_h, (size_t)R * 8, hipMemcpyHostToDevice, ctx->stream));
+        a.coeffs = coeffs_d.as<int64_t>();
+        a.part_int = pint.as<uint64_t>();
+    }
+    if (do_field) {
+        if ((rc = q0_d.get((size_t)R * FL * 8))) return rc;
+        if ((rc = pa.get((size_t)chunks * C * (FL + 2) * 8))) return rc;
+        if ((rc = pb.get((size_t)chunks * C * (FL + 1) * 8))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(q0_d.ptr, q0_h, (size_t)R * FL * 8, hipMemcpyHostToDevice, ctx->stream));
+        a.q0 = q0_d.as<uint64_t>();
+        a.part_a = pa.as<uint64_t>();
+        a.part_b = pb.as<uint64_t>();
+    }
+    {
+        LaunchTimer t(ctx, "combine_rows_kernel");
+        const dim3 grid(bx, chunks), block(256);
+        if (do_int && do_field)
+            hipLaunchKernelGGL((combine_rows_kernel<FL, true, true>), grid, block, 0, ctx->stream, a);
+        else if (do_int)
+            hipLaunchKernelGGL((combine_rows_kernel<FL, true, false>), grid, block, 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((combine_rows_kernel<FL, false, true>), grid, block, 0, ctx->stream, a);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    FinalizeArgs fa{};
+    fa.part_int = a.part_int;
+    fa.part_a = a.part_a;
+    fa.part_b = a.part_b;
+    fa.chunks = chunks;
+    fa.row_len = C;
+    fa.m_limbs = ctx->p.m_limbs;
+    fa.uprime = out.uprime;
+    fa.row_limbs = out.row_limbs;
+    fa.row_be = out.row_be;
+    FieldDev<FL> fd{};
+    if (hf) fd = to_dev<FL>(*hf);
+    {
+        LaunchTimer t(ctx, "combine_finalize_kernel");
+        const dim3 grid(bx), block(256);
+        if (do_int && do_field)
+            hipLaunchKernelGGL((combine_finalize_kernel<FL, true, true>), grid, block, 0, ctx->stream, fa, fd);
+        else if (do_int)
+            hipLaunchKernelGGL((combine_finalize_kernel<FL, true, false>), grid, block, 0, ctx->stream, fa, fd);
+        else
+            hipLaunchKernelGGL((combine_finalize_kernel<FL, false, true>), grid, block, 0, ctx->stream, fa, fd);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    // the H2D copies above read pageable host memory; make sure they are done before returning
+    // control to a caller that may free coeffs / q0 (hipMemcpyAsync from pageable memory is
+    // staged, but be explicit)
+    return ZIP_OK;
+}
+
+int32_t run_combine(zip_ctx *ctx, const int64_t *evals_d, const int64_t *coeffs_h, const uint64_t *q0_h,
+                    const HostField *hf, bool do_int, bool do_field, const CombineOut &out) {
+    const uint32_t fl = hf ? hf->fl : 4;
+    switch (fl) {
+        case 2: return run_combine_fl<2>(ctx, evals_d, coeffs_h, q0_h, hf, do_int, do_field, out);
+        case 3: return run_combine_fl<3>(ctx, evals_d, coeffs_h, q0_h, hf, do_int, do_field, out);
+        default: return run_combine_fl<4>(ctx, evals_d, coeffs_h, q0_h, hf, do_int, do_field, out);
+    }
+}
+
+int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_h, uint32_t n_cols, uint8_t *out_d) {
+    zip_ctx *ctx = c->ctx;
+    if (n_cols == 0) return ZIP_OK;
+    for (uint32_t i = 0; i < n_cols; i++)
+        if (cols_h[i] >= ctx->p.codeword_len)
+            return fail(ctx, ZIP_ERR_INVALID_PARAM, "column index %u out of range (codeword_len %u)", cols_h[i],
+                        ctx->p.codeword_len);
+    Scratch cols_d(ctx);
+    int32_t rc;
+    if ((rc = cols_d.get((size_t)n_cols * 4))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(cols_d.ptr, cols_h, (size_t)n_cols * 4, hipMemcpyHostToDevice, ctx->stream));
+    OpenColsArgs a{};
+    a.rows = c->rows;
+    a.layers = reinterpret_cast<const uint64_t *>(c->layers);
+    a.cols = cols_d.as<uint32_t>();
+    a.out = out_d;
+    a.num_rows = ctx->rows_local;
+    a.cw = ctx->p.codeword_len;
+    a.depth = ctx->depth;
+    a.k_limbs = ctx->p.k_limbs;
+    a.rows_per_block = 64;
+    const dim3 grid(n_cols, (ctx->rows_local + a.rows_per_block - 1) / a.rows_per_block), block(256);
+    LaunchTimer t(ctx, "open_columns_kernel");
+    hipLaunchKernelGGL(open_columns_kernel, grid, block, 0, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return ZIP_OK;
+}
+
+size_t column_bytes(const zip_ctx *ctx) {
+    return (size_t)ctx->rows_local * (8 * (size_t)ctx->p.k_limbs + 8 + 32 * (size_t)ctx->depth);
+}
+
+// copies a device result to the caller's buffer (host: synchronous)
+int32_t deliver(zip_ctx *ctx, void *dst, zip_mem_kind kind, const void *src_d, size_t bytes) {
+    if (kind == ZIP_MEM_HOST) {
+        HIP_TRY(ctx, hipMemcpyAsync(dst, src_d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    } else if (dst != src_d) {
+        HIP_TRY(ctx, hipMemcpyAsync(dst, src_d, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return ZIP_OK;
+}
+
+}  // namespace
+
+// =============================================================================
+// exported symbols
+// =============================================================================
+extern "C" {
+
+int32_t zip_abi_version(void) { return ZIP_HIP_ABI_VERSION; }
+
+const char *zip_strerror(int32_t code) {
+    switch (code) {
+        case ZIP_OK: return "ok";
+        case ZIP_ERR_INVALID_PARAM: return "invalid PCS parameter";
+        case ZIP_ERR_SHAPE: return "shape mismatch (the reference panics here)";
+        case ZIP_ERR_HIP: return "HIP runtime error";
+        case ZIP_ERR_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
+        case ZIP_ERR_UNSUPPORTED: return "unsupported geometry";
+        case ZIP_ERR_ALLOC: return "device allocation failed";
+        case ZIP_ERR_NULL: return "null argument";
+        default: return "unknown error";
+    }
+}
+
+int32_t zip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t zip_ctx_create(const zip_params *p, zip_ctx **out) {
+    if (!p || !out) return ZIP_ERR_NULL;
+    *out = nullptr;
+    // ---- geometry checks (no GPU needed) ----
+    if (p->n_limbs != 1 || p->k_limbs != 4 || p->m_limbs != 8) return ZIP_ERR_UNSUPPORTED;
+    if (!is_pow2(p->row_len) || !is_pow2(p->rep) || !is_pow2(p->num_rows)) return ZIP_ERR_INVALID_PARAM;
+    if ((uint64_t)p->row_len * p->rep != p->codeword_len) return ZIP_ERR_INVALID_PARAM;
+    if (p->num_vars > 40 || (uint64_t)p->row_len * p->num_rows != (1ull << p->num_vars)) return ZIP_ERR_INVALID_PARAM;
+    {
+        // RaaCode::new width assertion, src/zip/code_raa.rs:53-72
+        const uint32_t nv_even = (p->num_vars & 1) ? p->num_vars + 1 : p->num_vars;
+        const uint32_t width = 64 * p->n_limbs + nv_even + 2 * ilog2(p->rep);
+        if (width > 64 * p->k_limbs) return ZIP_ERR_INVALID_PARAM;
+    }
+    if (p->codeword_len > 16384) return ZIP_ERR_UNSUPPORTED;  // 96-bit lanes + one workgroup per row
+    if (!p->perm1 || !p->perm2) return ZIP_ERR_NULL;
+    const uint32_t rows_local = p->row_count ? p->row_count : p->num_rows;
+    if ((uint64_t)p->row_begin + rows_local > p->num_rows) return ZIP_ERR_INVALID_PARAM;
+    {
+        std::vector<uint8_t> seen(p->codeword_len);
+        for (int k = 0; k < 2; k++) {
+            const uint32_t *perm = k ? p->perm2 : p->perm1;
+            std::fill(seen.begin(), seen.end(), 0);
+            for (uint32_t j = 0; j < p->codeword_len; j++) {
+                if (perm[j] >= p->codeword_len || seen[perm[j]]) return ZIP_ERR_INVALID_PARAM;
+                seen[perm[j]] = 1;
+            }
+        }
+    }
+    // ---- device ----
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ZIP_ERR_NO_DEVICE;
+    if (p->device < 0 || p->device >= ndev) return ZIP_ERR_NO_DEVICE;
+    zip_ctx *ctx = new (std::nothrow) zip_ctx();
+    if (!ctx) return ZIP_ERR_ALLOC;
+    ctx->p = *p;
+    ctx->p.perm1 = ctx->p.perm2 = nullptr;
+    ctx->device = p->device;
+    ctx->depth = ilog2(p->codeword_len);  // codeword_len.next_power_of_two().ilog2(), commit.rs:67
+    ctx->rows_local = rows_local;
+    int32_t rc = ZIP_OK;
+    do {
+        if (hipSetDevice(ctx->device) != hipSuccess) { rc = ZIP_ERR_NO_DEVICE; break; }
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
+        const size_t pb = (size_t)p->codeword_len * 4;
+        if (hipMalloc((void **)&ctx->perm1_d, pb) != hipSuccess || hipMalloc((void **)&ctx->perm2_d, pb) != hipSuccess) {
+            rc = ZIP_ERR_ALLOC;
+            break;
+        }
+        if (hipMemcpy(ctx->perm1_d, p->perm1, pb, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(ctx->perm2_d, p->perm2, pb, hipMemcpyHostToDevice) != hipSuccess) {
+            rc = ZIP_ERR_HIP;
+            break;
+        }
+    } while (0);
+    if (rc) {
+        zip_ctx_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return ZIP_OK;
+}
+
+void zip_ctx_destroy(zip_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
+    for (auto &kv : ctx->live_blocks) (void)hipFree(kv.first);
+    for (auto &pe : ctx->pending) {
+        (void)hipEventDestroy(pe.start);
+        (void)hipEventDestroy(pe.stop);
+    }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->perm1_d) (void)hipFree(ctx->perm1_d);
+    if (ctx->perm2_d) (void)hipFree(ctx->perm2_d);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *zip_ctx_last_error(const zip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int32_t zip_ctx_synchronize(zip_ctx *ctx) {
+    if (!ctx) return ZIP_ERR_NULL;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ZIP_OK;
+}
+
+void *zip_ctx_stream(zip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
+                   int32_t with_merkle, uint8_t *roots_out, zip_commitment **out) {
+    if (!ctx || !out) return ZIP_ERR_NULL;
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t R = ctx->rows_local, C = ctx->p.row_len, cw = ctx->p.codeword_len;
+    if (n_evals != (size_t)R * C)
+        return fail(ctx, ZIP_ERR_SHAPE,
+                    "Polynomial has an incorrect number of evaluations (%zu) for the expected matrix size (%zu)",
+                    n_evals, (size_t)R * C);
+    zip_commitment *c = new (std::nothrow) zip_commitment();
+    if (!c) return ZIP_ERR_ALLOC;
+    c->ctx = ctx;
+    int32_t rc = ZIP_OK;
+    do {
+        c->rows_bytes = (size_t)R * cw * 32;
+        if ((rc = pool_alloc(ctx, c->rows_bytes, (void **)&c->rows))) break;
+        if (with_merkle) {
+            c->layers_bytes = (size_t)R * 2 * cw * 32;
+            c->roots_bytes = (size_t)R * 32;
+            if ((rc = pool_alloc(ctx, c->layers_bytes, (void **)&c->layers))) break;
+            if ((rc = pool_alloc(ctx, c->roots_bytes, (void **)&c->roots))) break;
+        }
+        const int64_t *evals_d = evals;
+        if (!evals) { rc = fail(ctx, ZIP_ERR_NULL, "evals is NULL"); break; }
+        if (evals_kind == ZIP_MEM_HOST) {
+            c->evals_bytes = n_evals * 8;
+            if ((rc = pool_alloc(ctx, c->evals_bytes, (void **)&c->evals))) break;
+            hipError_t e = hipMemcpyAsync(c->evals, evals, c->evals_bytes, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "witness upload failed: %s", hipGetErrorString(e)); break; }
+            evals_d = c->evals;
+        }
+        CommitArgs a{};
+        a.evals = evals_d;
+        a.perm1 = ctx->perm1_d;
+        a.perm2 = ctx->perm2_d;
+        a.rows = c->rows;
+        a.layers = c->layers;
+        a.row_len = C;
+        a.cw = cw;
+        uint32_t levels_done = 0;
+        rc = with_merkle ? dispatch_commit<true>(ctx, a, &levels_done) : dispatch_commit<false>(ctx, a, &levels_done);
+        if (rc) break;
+        if (with_merkle) {
+            if ((rc = merkle_upper_levels(ctx, c->layers, c->roots, R, cw, levels_done, ctx->depth))) break;
+            if (roots_out) {
+                if ((rc = deliver(ctx, roots_out, ZIP_MEM_HOST, c->roots, c->roots_bytes))) break;
+            }
+        }
+        if (evals_kind == ZIP_MEM_HOST) {
+            hipError_t e = hipStreamSynchronize(ctx->stream);  // the caller's buffer is free to go
+            if (e != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "commit failed: %s", hipGetErrorString(e)); break; }
+        }
+    } while (0);
+    if (rc) {
+        zip_commitment_free(c);
+        return rc;
+    }
+    *out = c;
+    return ZIP_OK;
+}
+
+void zip_commitment_free(zip_commitment *c) {
+    if (!c) return;
+    pool_release(c->ctx, c->rows);
+    pool_release(c->ctx, c->layers);
+    pool_release(c->ctx, c->roots);
+    pool_release(c->ctx, c->evals);
+    delete c;
+}
+
+int32_t zip_commitment_device_ptrs(zip_commitment *c, uint64_t **rows, uint8_t **layers, uint8_t **roots) {
+    if (!c) return ZIP_ERR_NULL;
+    if (rows) *rows = c->rows;
+    if (layers) *layers = reinterpret_cast<uint8_t *>(c->layers);
+    if (roots) *roots = reinterpret_cast<uint8_t *>(c->roots);
+    return ZIP_OK;
+}
+
+int32_t zip_commit_download(zip_commitment *c, uint64_t *rows_out, uint8_t *layers_out, uint8_t *roots_out) {
+    if (!c) return ZIP_ERR_NULL;
+    zip_ctx *ctx = c->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t R = ctx->rows_local, cw = ctx->p.codeword_len;
+    if (rows_out) HIP_TRY(ctx, hipMemcpyAsync(rows_out, c->rows, c->rows_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (layers_out) {
+        if (!c->layers) return fail(ctx, ZIP_ERR_INVALID_PARAM, "commitment has no Merkle trees (commit_no_merkle)");
+        const size_t w = ((size_t)2 * cw - 2) * 32;
+        if (w)
+            HIP_TRY(ctx, hipMemcpy2DAsync(layers_out, w, c->layers, (size_t)2 * cw * 32, w, R, hipMemcpyDeviceToHost,
+                                          ctx->stream));
+    }
+    if (roots_out) {
+        if (!c->roots) return fail(ctx, ZIP_ERR_INVALID_PARAM, "commitment has no Merkle roots (commit_no_merkle)");
+        HIP_TRY(ctx, hipMemcpyAsync(roots_out, c->roots, c->roots_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ZIP_OK;
+}
+
+int32_t zip_commitment_upload(zip_ctx *ctx, const uint64_t *rows, const uint8_t *layers, const uint8_t *roots,
+                              zip_commitment **out) {
+    if (!ctx || !out || !rows) return ZIP_ERR_NULL;
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t R = ctx->rows_local, cw = ctx->p.codeword_len;
+    zip_commitment *c = new (std::nothrow) zip_commitment();
+    if (!c) return ZIP_ERR_ALLOC;
+    c->ctx = ctx;
+    int32_t rc = ZIP_OK;
+    do {
+        c->rows_bytes = (size_t)R * cw * 32;
+        if ((rc = pool_alloc(ctx, c->rows_bytes, (void **)&c->rows))) break;
+        hipError_t e = hipMemcpyAsync(c->rows, rows, c->rows_bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && layers) {
+            c->layers_bytes = (size_t)R * 2 * cw * 32;
+            c->roots_bytes = (size_t)R * 32;
+            if ((rc = pool_alloc(ctx, c->layers_bytes, (void **)&c->layers))) break;
+            if ((rc = pool_alloc(ctx, c->roots_bytes, (void **)&c->roots))) break;
+            const size_t w = ((size_t)2 * cw - 2) * 32;
+            if (w) e = hipMemcpy2DAsync(c->layers, (size_t)2 * cw * 32, layers, w, w, R, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess && roots) {
+                e = hipMemcpyAsync(c->roots, roots, c->roots_bytes, hipMemcpyHostToDevice, ctx->stream);
+                // keep the in-tree root slot consistent with the separate roots array
+                if (e == hipSuccess)
+                    e = hipMemcpy2DAsync(reinterpret_cast<uint8_t *>(c->layers) + ((size_t)2 * cw - 2) * 32,
+                                         (size_t)2 * cw * 32, roots, 32, 32, R, hipMemcpyHostToDevice, ctx->stream);
+            }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, ZIP_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+    } while (0);
+    if (rc) {
+        zip_commitment_free(c);
+        return rc;
+    }
+    *out = c;
+    return ZIP_OK;
+}
+
+int32_t zip_open_testing(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_kind, const int64_t *coeffs,
+                         uint64_t *uprime_out, zip_mem_kind out_kind) {
+    if (!ctx || !coeffs || !uprime_out) return ZIP_ERR_NULL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Scratch ev(ctx), res(ctx);
+    const int64_t *evals_d;
+    int32_t rc;
+    if ((rc = stage_evals(ctx, evals, evals_kind, (size_t)ctx->rows_local * ctx->p.row_len, ev, &evals_d))) return rc;
+    const size_t bytes = (size_t)ctx->p.row_len * ctx->p.m_limbs * 8;
+    CombineOut o{};
+    if (out_kind == ZIP_MEM_DEVICE) {
+        o.uprime = uprime_out;
+    } else {
+        if ((rc = res.get(bytes))) return rc;
+        o.uprime = res.as<uint64_t>();
+    }
+    if ((rc = run_combine(ctx, evals_d, coeffs, nullptr, nullptr, true, false, o))) return rc;
+    if (out_kind == ZIP_MEM_HOST) return deliver(ctx, uprime_out, ZIP_MEM_HOST, o.uprime, bytes);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // coeffs were read from host memory
+    return ZIP_OK;
+}
+
+int32_t zip_open_columns(zip_commitment *c, const uint32_t *cols, uint32_t n_cols, uint8_t *wire_out,
+                         zip_mem_kind out_kind) {
+    if (!c || !cols || !wire_out) return ZIP_ERR_NULL;
+    zip_ctx *ctx = c->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!c->layers) return fail(ctx, ZIP_ERR_INVALID_PARAM, "commitment has no Merkle trees (commit_no_merkle)");
+    const size_t bytes = (size_t)n_cols * column_bytes(ctx);
+    Scratch res(ctx);
+    uint8_t *out_d = wire_out;
+    int32_t rc;
+    if (out_kind == ZIP_MEM_HOST) {
+        if ((rc = res.get(bytes))) return rc;
+        out_d = res.as<uint8_t>();
+    }
+    if ((rc = run_open_columns(c, cols, n_cols, out_d))) return rc;
+    if (out_kind == ZIP_MEM_HOST) return deliver(ctx, wire_out, ZIP_MEM_HOST, out_d, bytes);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // cols were read from host memory
+    return ZIP_OK;
+}
+
+int32_t zip_open_eval(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_kind, const uint64_t *q0_mont,
+                      const zip_field *field, uint64_t *row_out, zip_mem_kind out_kind) {
+    if (!ctx || !row_out) return ZIP_ERR_NULL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HostField hf;
+    int32_t rc;
+    if ((rc = make_field(ctx, field, &hf))) return rc;
+    const bool single = ctx->p.num_rows == 1;
+    if (!single && !q0_mont) return fail(ctx, ZIP_ERR_NULL, "q0_mont is NULL");
+    Scratch ev(ctx), res(ctx);
+    const int64_t *evals_d;
+    if ((rc = stage_evals(ctx, evals, evals_kind, (size_t)ctx->rows_local * ctx->p.row_len, ev, &evals_d))) return rc;
+    const size_t bytes = (size_t)ctx->p.row_len * hf.fl * 8;
+    CombineOut o{};
+    if (out_kind == ZIP_MEM_DEVICE) {
+        o.row_limbs = row_out;
+    } else {
+        if ((rc = res.get(bytes))) return rc;
+        o.row_limbs = res.as<uint64_t>();
+    }
+    // one row: the evaluation row is map_to_field(evals) = 1_mont * w (open_z.rs:84-88)
+    if ((rc = run_combine(ctx, evals_d, nullptr, single ? hf.r : q0_mont, &hf, false, true, o))) return rc;
+    if (out_kind == ZIP_MEM_HOST) return deliver(ctx, row_out, ZIP_MEM_HOST, o.row_limbs, bytes);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ZIP_OK;
+}
+
+size_t zip_proof_len(const zip_ctx *ctx, uint32_t n_cols, uint32_t field_limbs) {
+    if (!ctx) return 0;
+    size_t len = 0;
+    if (ctx->p.num_rows > 1) len += (size_t)ctx->p.row_len * ctx->p.m_limbs * 8;
+    len += (size_t)n_cols * column_bytes(ctx);
+    len += (size_t)ctx->p.row_len * field_limbs * 8;
+    return len;
+}
+
+int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kind, const int64_t *coeffs,
+                 const uint32_t *cols, uint32_t n_cols, const uint64_t *q0_mont, const zip_field *field,
+                 uint8_t *proof_out, zip_mem_kind out_kind) {
+    if (!c || !proof_out || (n_cols && !cols)) return ZIP_ERR_NULL;
+    zip_ctx *ctx = c->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->rows_local != ctx->p.num_rows)
+        return fail(ctx, ZIP_ERR_INVALID_PARAM, "zip_open needs an unsharded ctx; use the per-phase calls on a row shard");
+    if (!c->layers) return fail(ctx, ZIP_ERR_INVALID_PARAM, "commitment has no Merkle trees (commit_no_merkle)");
+    HostField hf;
+    int32_t rc;
+    if ((rc = make_field(ctx, field, &hf))) return rc;
+    const bool single = ctx->p.num_rows == 1;
+    if (!single && (!coeffs || !q0_mont)) return fail(ctx, ZIP_ERR_NULL, "coeffs / q0_mont is NULL");
+    Scratch ev(ctx), res(ctx);
+    const int64_t *evals_d = c->evals;  // witness retained by a host-side commit
+    if (evals) {
+        if ((rc = stage_evals(ctx, evals, evals_kind, (size_t)ctx->rows_local * ctx->p.row_len, ev, &evals_d))) return rc;
+    } else if (!evals_d) {
+        return fail(ctx, ZIP_ERR_NULL, "evals is NULL and the commitment retains no witness");
+    }
+    const size_t total = zip_proof_len(ctx, n_cols, hf.fl);
+    uint8_t *out_d = proof_out;
+    if (out_kind == ZIP_MEM_HOST) {
+        if ((rc = res.get(total))) return rc;
+        out_d = res.as<uint8_t>();
+    }
+    const size_t u_bytes = single ? 0 : (size_t)ctx->p.row_len * ctx->p.m_limbs * 8;
+    const size_t col_bytes = (size_t)n_cols * column_bytes(ctx);
+    CombineOut o{};
+    o.uprime = single ? nullptr : reinterpret_cast<uint64_t *>(out_d);
+    o.row_be = out_d + u_bytes + col_bytes;
+    if ((rc = run_combine(ctx, evals_d, coeffs, single ? hf.r : q0_mont, &hf, !single, true, o))) return rc;
+    if ((rc = run_open_columns(c, cols, n_cols, out_d + u_bytes))) return rc;
+    if (out_kind == ZIP_MEM_HOST) return deliver(ctx, proof_out, ZIP_MEM_HOST, out_d, total);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // small host inputs (coeffs, cols, q0) were consumed
+    return ZIP_OK;
+}
+
+int32_t zip_sum_partials(zip_ctx *ctx, const uint64_t *uparts, const uint64_t *fparts, uint32_t n_parts,
+                         const zip_field *field, uint64_t *uprime_out, uint64_t *row_out) {
+    if (!ctx) return ZIP_ERR_NULL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if ((uparts && !uprime_out) || (fparts && !row_out)) return ZIP_ERR_NULL;
+    HostField hf;
+    hf.fl = 4;
+    int32_t rc;
+    if (fparts && (rc = make_field(ctx, field, &hf))) return rc;
+    const uint32_t C = ctx->p.row_len;
+    const dim3 grid((C + 255) / 256), block(256);
+    LaunchTimer t(ctx, "sum_partials_kernel");
+    switch (hf.fl) {
+        case 2:
+            hipLaunchKernelGGL(sum_partials_kernel<2>, grid, block, 0, ctx->stream, uparts, fparts, n_parts, C,
+                               ctx->p.m_limbs, uprime_out, row_out, to_dev<2>(hf));
+            break;
+        case 3:
+            hipLaunchKernelGGL(sum_partials_kernel<3>, grid, block, 0, ctx->stream, uparts, fparts, n_parts, C,
+                               ctx->p.m_limbs, uprime_out, row_out, to_dev<3>(hf));
+            break;
+        default:
+            hipLaunchKernelGGL(sum_partials_kernel<4>, grid, block, 0, ctx->stream, uparts, fparts, n_parts, C,
+                               ctx->p.m_limbs, uprime_out, row_out, to_dev<4>(hf));
+            break;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return ZIP_OK;
+}
+
+int32_t zip_merkle_trees(int32_t device, const uint64_t *leaves, uint32_t leaf_limbs, uint32_t depth,
+                         uint32_t num_trees, zip_mem_kind kind, uint8_t *layers_out) {
+    if (!leaves || !layers_out) return ZIP_ERR_NULL;
+    if (leaf_limbs < 1 || leaf_limbs > 8 || depth > 24 || num_trees == 0) return ZIP_ERR_INVALID_PARAM;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return ZIP_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return ZIP_ERR_NO_DEVICE;
+    // a throw-away ctx gives us the stream / pool / error plumbing
+    zip_ctx *ctx = new (std::nothrow) zip_ctx();
+    if (!ctx) return ZIP_ERR_ALLOC;
+    ctx->device = device;
+    int32_t rc = ZIP_OK;
+    const uint32_t n = 1u << depth;
+    const size_t leaf_bytes = (size_t)num_trees * n * leaf_limbs * 8;
+    const size_t tree_bytes = (size_t)num_trees * 2 * n * 32;
+    const size_t out_w = ((size_t)2 * n - 1) * 32;
+    void *leaves_d = nullptr, *layers_d = nullptr, *roots_d = nullptr;
+    do {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
+        if (kind == ZIP_MEM_HOST) {
+            if ((rc = pool_alloc(ctx, leaf_bytes, &leaves_d))) break;
+            if (hipMemcpyAsync(leaves_d, leaves, leaf_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
+        } else {
+            leaves_d = const_cast<uint64_t *>(leaves);
+        }
+        if ((rc = pool_alloc(ctx, tree_bytes, &layers_d))) break;
+        if ((rc = pool_alloc(ctx, (size_t)num_trees * 32, &roots_d))) break;
+        const size_t total = (size_t)num_trees * n;
+        const dim3 grid((uint32_t)((total + 255) / 256)), block(256);
+        const uint64_t *L = static_cast<const uint64_t *>(leaves_d);
+        uint32_t *Y = static_cast<uint32_t *>(layers_d);
+        switch (leaf_limbs) {
+            case 1: hipLaunchKernelGGL(merkle_leaves_kernel<1>, grid, block, 0, ctx->stream, L, Y, num_trees, n); break;
+            case 2: hipLaunchKernelGGL(merkle_leaves_kernel<2>, grid, block, 0, ctx->stream, L, Y, num_trees, n); break;
+            case 3: hipLaunchKernelGGL(merkle_leaves_kernel<3>, grid, block, 0, ctx->stream, L, Y, num_trees, n); break;
+            case 4: hipLaunchKernelGGL(merkle_leaves_kernel<4>, grid, block, 0, ctx->stream, L, Y, num_trees, n); break;
+            case 5: hipLaunchKernelGGL(merkle_leaves_kernel<5>, grid, block, 0, ctx->stream, L, Y, num_trees, n); break;
+            case 6: hipLaunchKernelGGL(merkle_leaves_kernel<6>, grid, block, 0, ctx->stream, L, Y, num_trees, n); break;
+            case 7: hipLaunchKernelGGL(merkle_leaves_kernel<7>, grid, block, 0, ctx->stream, L, Y, num_trees, n); break;
+            default: hipLaunchKernelGGL(merkle_leaves_kernel<8>, grid, block, 0, ctx->stream, L, Y, num_trees, n); break;
+        }
+        if (hipGetLastError() != hipSuccess) { rc = ZIP_ERR_HIP; break; }
+        if ((rc = merkle_upper_levels(ctx, Y, static_cast<uint32_t *>(roots_d), num_trees, n, 0, depth))) break;
+        hipError_t e = hipMemcpy2DAsync(layers_out, out_w, layers_d, (size_t)2 * n * 32, out_w, num_trees,
+                                        kind == ZIP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                                        ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = ZIP_ERR_HIP;
+    } while (0);
+    if (kind != ZIP_MEM_HOST) {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        ctx->live_blocks.erase(leaves_d);  // not ours
+    }
+    zip_ctx_destroy(ctx);
+    return rc;
+}
+
+int32_t zip_ctx_set_profiling(zip_ctx *ctx, int32_t on) {
+    if (!ctx) return ZIP_ERR_NULL;
+    ctx->profiling = on != 0;
+    return ZIP_OK;
+}
+
+int32_t zip_ctx_profile_read(zip_ctx *ctx, zip_kernel_time *out, uint32_t cap) {
+    if (!ctx) return ZIP_ERR_NULL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &pe : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) {
+            KernelStat &s = ctx->stats[pe.name];
+            s.launches++;
+            s.total_ms += ms;
+        }
+        ctx->event_pool.push_back(pe.start);
+        ctx->event_pool.push_back(pe.stop);
+    }
+    ctx->pending.clear();
+    ctx->stat_names.clear();
+    ctx->stat_names.reserve(ctx->stats.size());
+    uint32_t n = 0;
+    for (auto &kv : ctx->stats) {
+        ctx->stat_names.push_back(kv.first);
+        if (out && n < cap) {
+            out[n].name = ctx->stat_names.back().c_str();
+            out[n].launches = kv.second.launches;
+            out[n].total_ms = kv.second.total_ms;
+        }
+        n++;
+    }
+    ctx->stats.clear();
+    return (int32_t)n;
+}
+
+}  // extern "C"
