@@ -64,6 +64,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1.  Loading ours
+        # first would put TWO HIP runtimes in the process (torch then sees "No HIP GPUs").
+        # With torch's already mapped, the loader resolves our NEEDED sonames to the same copy.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m zinc_amd.build` "
