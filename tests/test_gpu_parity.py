@@ -193,8 +193,9 @@ def test_full_open_proof_equals_oracle_and_verifies(cabi, num_vars, modulus, fl)
     proof = com.open(evals, coeffs if z.num_rows > 1 else None, cols, q0, cabi.make_field(modulus, fl))
     assert proof.size == proof_o.size == z.proof_len(fl)
     assert np.array_equal(proof, proof_o)
-    ev = z.mle_eval(f, evals, point)
-    assert z.verify(f, roots, point, ev, proof) == 0
+    if num_vars > 0:  # row_len == 1 leaves q_1 empty: the reference's own verifier cannot accept (verify_z.rs:146-151)
+        ev = z.mle_eval(f, evals, point)
+        assert z.verify(f, roots, point, ev, proof) == 0
 
 
 def test_open_from_uploaded_and_mutated_commitment(cabi):

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-kernel HIP-event times through the C ABI's measurement hooks (GPU box)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from zinc_amd import cabi  # noqa: E402
+from zinc_amd.perm import shuffle_seeded_perm  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num-vars", type=int, default=24)
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    import torch
+
+    nv = args.num_vars
+    row_len, num_rows, cw = cabi.geometry(nv)
+    ctx = cabi.ZipContext(nv, shuffle_seeded_perm(1, cw), shuffle_seeded_perm(2, cw))
+    zf = cabi.make_field(bench.BENCH_MODULUS, 4)
+    coeffs, cols, q0 = bench.host_inputs(nv, row_len, num_rows, cw, 4, 1)
+    evals = torch.from_numpy(bench.splitmix64(7, 1 << nv).copy()).cuda()
+    proof = torch.empty(ctx.proof_len(1000, 4), dtype=torch.uint8, device="cuda")
+    for rep in range(args.reps + 1):
+        if rep == 1:
+            ctx.set_profiling(True)
+        com, _ = ctx.commit(evals, want_roots=False)
+        com.open(evals, coeffs, cols, q0, zf, out=proof)
+        com.free()
+        c2, _ = ctx.commit(evals, with_merkle=False)
+        c2.free()
+    ctx.synchronize()
+    t = ctx.profile_read()
+    for k, (n, ms) in sorted(t.items()):
+        print(f"{k:28s} launches {n:3d}  avg {ms / n:8.4f} ms")
+
+
+if __name__ == "__main__":
+    main()

@@ -218,12 +218,14 @@ class ZipContext:
         return Commitment(self, h, bool(with_merkle)), roots
 
     def upload_commitment(self, rows, layers=None, roots=None):
+        # keep every (possibly copied) array alive across the call
         rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        layers_c = None if layers is None else np.ascontiguousarray(layers, dtype=np.uint8)
+        roots_c = None if roots is None else np.ascontiguousarray(roots, dtype=np.uint8)
         h = C.c_void_p()
         rc = lib().zip_commitment_upload(
-            self._h, rows.ctypes.data,
-            None if layers is None else np.ascontiguousarray(layers, dtype=np.uint8).ctypes.data,
-            None if roots is None else np.ascontiguousarray(roots, dtype=np.uint8).ctypes.data, C.byref(h))
+            self._h, rows.ctypes.data, None if layers_c is None else layers_c.ctypes.data,
+            None if roots_c is None else roots_c.ctypes.data, C.byref(h))
         self._check(rc, "zip_commitment_upload")
         return Commitment(self, h, layers is not None)
 
@@ -319,7 +321,8 @@ class Commitment:
         c = self.ctx
         ptr, kind = _ptr(evals)
         cols = np.ascontiguousarray(cols, dtype=np.uint32)
-        cp = np.ascontiguousarray(coeffs, dtype=np.int64).ctypes.data if coeffs is not None else None
+        coeffs_c = np.ascontiguousarray(coeffs, dtype=np.int64) if coeffs is not None else None
+        cp = coeffs_c.ctypes.data if coeffs_c is not None else None
         q0 = np.ascontiguousarray(q0_mont, dtype=np.uint64) if q0_mont is not None else None
         total = c.proof_len(cols.size, field.limbs)
         res = out if out is not None else np.zeros(total, dtype=np.uint8)

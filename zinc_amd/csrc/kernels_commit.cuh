@@ -111,6 +111,54 @@ struct CommitLeaves {
     }
 };
 
+// Strided ownership for the output phase: at step e lane t owns codeword entry
+// j = e*T + t, so the 32-byte row entries, leaf hashes and nodes that a wave stores in one
+// instruction are adjacent in memory (4 lanes per 128-byte line instead of one lane per
+// line).  Sibling leaves then sit in NEIGHBOUR LANES; the in-thread subtree becomes a
+// butterfly: at level l a lane exchanges one child hash with lane t ^ 2^(l-1) and ends up
+// with the node of step E0 + (t mod 2^l).  Every lane still hashes E leaves, E/2 ... 1 nodes.
+template <int E>
+struct StridedLeaves {
+    uint32_t w0[E], w1[E], w2[E];  // 96-bit two's-complement values of the lane's E entries
+    uint64_t *out_row;
+    uint32_t *tree;
+    uint32_t cw, T, tid;
+    template <int E0>
+    __device__ __forceinline__ void leaf(uint32_t (&h)[8]) {
+        const uint32_t j = E0 * T + tid;
+        const uint32_t s = (uint32_t)((int32_t)w2[E0] >> 31);
+        uint4 *o = reinterpret_cast<uint4 *>(out_row + (size_t)j * 4);
+        o[0] = make_uint4(w0[E0], w1[E0], w2[E0], s);  // sign extension to Int<4>
+        o[1] = make_uint4(s, s, s, s);
+        blake3_leaf_sext96(w0[E0], w1[E0], w2[E0], h);
+        store_hash(tree + (size_t)j * 8, h);
+    }
+    __device__ __forceinline__ void store(int lvl, uint32_t e, const uint32_t (&h)[8]) {
+        store_hash(tree + ((size_t)level_off(cw, lvl) + ((e * T + tid) >> lvl)) * 8, h);
+    }
+};
+
+template <int LVL, int E0, class Src>
+__device__ __forceinline__ void bfly_hash(Src &src, uint32_t (&h)[8]) {
+    if constexpr (LVL == 0) {
+        src.template leaf<E0>(h);
+    } else {
+        uint32_t A[8], B[8], m[16];
+        bfly_hash<LVL - 1, E0>(src, A);
+        bfly_hash<LVL - 1, E0 + (1 << (LVL - 1))>(src, B);
+        const bool up = (src.tid >> (LVL - 1)) & 1;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t snd = up ? A[i] : B[i];
+            const uint32_t rcv = __shfl_xor(snd, 1 << (LVL - 1), 64);
+            m[i] = up ? rcv : A[i];      // left child
+            m[8 + i] = up ? B[i] : rcv;  // right child
+        }
+        blake3_block(m, 64u, h);
+        src.store(LVL, E0 + (src.tid & ((1u << LVL) - 1u)), h);
+    }
+}
+
 // One workgroup per witness row; thread t owns the E consecutive codeword entries
 // [t*E, t*E+E).  Values never exceed 64 + 2*log2(cw) + 1 <= 96 bits (width
 // assertion src/zip/code_raa.rs:53-72), so scans run on i128 lanes and the 256-bit
@@ -119,8 +167,9 @@ struct CommitLeaves {
 //                   (cw*12 + row_len*8 bytes; up to cw = 8192).
 //   T2_LDS = false: t2 is parked in the (not yet written) output row in HBM/L2
 //                   and the witness row is gathered from global memory.
-// In LDS, t2[j] sits at slot (j % E) * T + j / E so that the writes of a wave are
-// bank-conflict free; the pi2 gather is random either way.
+// In LDS, entry j sits at slot (j % E) * (T + 32/E) + j / E: the thread-contiguous writes
+// of a wave are bank-conflict free, and so are the strided reads (entry e*T + t) of the
+// output phase; the pi2 gather is random either way.
 template <int E, bool HASH, bool T2_LDS>
 __global__ void __launch_bounds__(1024) raa_commit_kernel(CommitArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -128,15 +177,17 @@ __global__ void __launch_bounds__(1024) raa_commit_kernel(CommitArgs a) {
     static_assert((1 << LOGE) == E, "E must be a power of two <= 16");
 
     const uint32_t tid = threadIdx.x, T = blockDim.x;
+    constexpr uint32_t PAD = 32 / E;
+    const uint32_t PS = T + PAD;  // plane stride (slots)
     const uint32_t row = blockIdx.x;
     const uint32_t cw = a.cw, row_len = a.row_len;
     const bool active = tid < a.nact;
     const uint32_t j0 = tid * E;
 
     i128 *wave_tot = reinterpret_cast<i128 *>(smem);                  // 16 entries
-    uint64_t *t2lo = reinterpret_cast<uint64_t *>(smem + 256);         // cw
-    uint32_t *t2hi = reinterpret_cast<uint32_t *>(t2lo + (T2_LDS ? cw : 0));
-    int64_t *rowbuf = reinterpret_cast<int64_t *>(t2hi + (T2_LDS ? cw : 0));
+    uint64_t *t2lo = reinterpret_cast<uint64_t *>(smem + 256);         // E planes of PS slots
+    uint32_t *t2hi = reinterpret_cast<uint32_t *>(t2lo + (T2_LDS ? E * PS : 0));
+    int64_t *rowbuf = reinterpret_cast<int64_t *>(t2hi + (T2_LDS ? E * PS : 0));
 
     const int64_t *in = a.evals + (size_t)row * row_len;
     uint64_t *out_row = a.rows + (size_t)row * cw * 4;
@@ -168,7 +219,7 @@ __global__ void __launch_bounds__(1024) raa_commit_kernel(CommitArgs a) {
             for (int e = 0; e < E; e++) {
                 v[e] += pre;
                 if (T2_LDS) {
-                    const uint32_t slot = e * T + tid;
+                    const uint32_t slot = e * PS + tid;
                     t2lo[slot] = (uint64_t)v[e];
                     t2hi[slot] = (uint32_t)((u128)v[e] >> 64);
                 } else {
@@ -184,7 +235,7 @@ __global__ void __launch_bounds__(1024) raa_commit_kernel(CommitArgs a) {
         for (int e = 0; e < E; e++) {
             const uint32_t src = a.perm2[j0 + e];
             if (T2_LDS) {
-                const uint32_t slot = (src & (E - 1)) * T + (src >> LOGE);
+                const uint32_t slot = (src & (E - 1)) * PS + (src >> LOGE);
                 const uint64_t lo = t2lo[slot];
                 const int64_t hi = (int64_t)(int32_t)t2hi[slot];
                 v[e] = (i128)(((u128)(uint64_t)hi << 64) | lo);
@@ -201,22 +252,65 @@ __global__ void __launch_bounds__(1024) raa_commit_kernel(CommitArgs a) {
 #pragma unroll
         for (int e = 0; e < E; e++) v[e] += pre;
     }
-    if (!active) return;
-
-    // ---- outputs: 256-bit rows, leaf hashes, in-thread subtree ------------------
-    uint4 *orow = reinterpret_cast<uint4 *>(out_row + (size_t)j0 * 4);
+    if (T2_LDS) {
+        // ---- transpose to strided ownership through LDS, then rows + hashes ----------
+        // (the second barrier inside the scan above already ordered every pi2 gather of t2
+        // before these writes)
+        if (active) {
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        const uint32_t d0 = (uint32_t)v[e], d1 = (uint32_t)((u128)v[e] >> 32),
-                       d2 = (uint32_t)((u128)v[e] >> 64);
-        const uint32_t s = (uint32_t)((int32_t)d2 >> 31);
-        orow[2 * e] = make_uint4(d0, d1, d2, s);
-        orow[2 * e + 1] = make_uint4(s, s, s, s);
-    }
-    if (HASH) {
-        CommitLeaves<E> src{v, a.layers + (size_t)row * (2u * cw) * 8, cw, j0};
-        uint32_t top[8];
-        subtree_hash<LOGE, 0>(src, top);
+            for (int e = 0; e < E; e++) {
+                const uint32_t slot = e * PS + tid;
+                t2lo[slot] = (uint64_t)v[e];
+                t2hi[slot] = (uint32_t)((u128)v[e] >> 64);
+            }
+        }
+        __syncthreads();
+        if (!active) return;
+        StridedLeaves<E> src;
+        src.out_row = out_row;
+        src.tree = HASH ? a.layers + (size_t)row * (2u * cw) * 8 : nullptr;
+        src.cw = cw;
+        src.T = a.nact;
+        src.tid = tid;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const uint32_t j = e * a.nact + tid;
+            const uint32_t slot = (j & (E - 1)) * PS + (j >> LOGE);
+            const uint64_t lo = t2lo[slot];
+            src.w0[e] = (uint32_t)lo;
+            src.w1[e] = (uint32_t)(lo >> 32);
+            src.w2[e] = t2hi[slot];
+        }
+        if (HASH) {
+            uint32_t top[8];
+            bfly_hash<LOGE, 0>(src, top);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const uint32_t j = e * a.nact + tid;
+                const uint32_t sg = (uint32_t)((int32_t)src.w2[e] >> 31);
+                uint4 *o = reinterpret_cast<uint4 *>(out_row + (size_t)j * 4);
+                o[0] = make_uint4(src.w0[e], src.w1[e], src.w2[e], sg);
+                o[1] = make_uint4(sg, sg, sg, sg);
+            }
+        }
+    } else {
+        if (!active) return;
+        // ---- thread-contiguous outputs (cw too large for the LDS transposition) -----
+        uint4 *orow = reinterpret_cast<uint4 *>(out_row + (size_t)j0 * 4);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const uint32_t d0 = (uint32_t)v[e], d1 = (uint32_t)((u128)v[e] >> 32),
+                           d2 = (uint32_t)((u128)v[e] >> 64);
+            const uint32_t sg = (uint32_t)((int32_t)d2 >> 31);
+            orow[2 * e] = make_uint4(d0, d1, d2, sg);
+            orow[2 * e + 1] = make_uint4(sg, sg, sg, sg);
+        }
+        if (HASH) {
+            CommitLeaves<E> src{v, a.layers + (size_t)row * (2u * cw) * 8, cw, j0};
+            uint32_t top[8];
+            subtree_hash<LOGE, 0>(src, top);
+        }
     }
 }
 

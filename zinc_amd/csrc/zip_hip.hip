@@ -46,6 +46,10 @@ struct zip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     uint32_t *perm1_d = nullptr, *perm2_d = nullptr;
+    // pinned host staging for the small per-call inputs (coeffs, q0, column indices): one
+    // truly asynchronous H2D copy instead of several pageable (blocking, staged) ones
+    unsigned char *stage_h = nullptr;
+    size_t stage_cap = 0;
     std::string last_error;
     // caching allocator: exact-size free lists
     std::multimap<size_t, void *> free_blocks;
@@ -133,6 +137,39 @@ struct Scratch {
     template <class T>
     T *as() { return static_cast<T *>(ptr); }
 };
+
+// Copies up to three small host arrays into ONE device block through the pinned staging
+// buffer.  The staging buffer is reused by the next call, so every caller synchronises the
+// stream before returning (they all do: host inputs must be consumed before we return).
+struct SmallInputs {
+    const void *src[3] = {nullptr, nullptr, nullptr};
+    size_t bytes[3] = {0, 0, 0};
+    size_t off[3] = {0, 0, 0};
+};
+int32_t stage_small(zip_ctx *ctx, SmallInputs &in, Scratch &dev, unsigned char **base) {
+    size_t total = 0;
+    for (int i = 0; i < 3; i++) {
+        in.off[i] = total;
+        total += (in.bytes[i] + 255) & ~(size_t)255;
+    }
+    if (total == 0) { *base = nullptr; return ZIP_OK; }
+    if (total > ctx->stage_cap) {
+        if (ctx->stage_h) (void)hipHostFree(ctx->stage_h);
+        ctx->stage_h = nullptr;
+        ctx->stage_cap = 0;
+        size_t cap = total < (1u << 20) ? (1u << 20) : total;
+        hipError_t e = hipHostMalloc((void **)&ctx->stage_h, cap, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(ctx, ZIP_ERR_ALLOC, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+        ctx->stage_cap = cap;
+    }
+    for (int i = 0; i < 3; i++)
+        if (in.bytes[i]) memcpy(ctx->stage_h + in.off[i], in.src[i], in.bytes[i]);
+    int32_t rc = dev.get(total);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(dev.ptr, ctx->stage_h, total, hipMemcpyHostToDevice, ctx->stream));
+    *base = dev.as<unsigned char>();
+    return ZIP_OK;
+}
 
 // ------------------------------------------------------------------ measurement
 hipEvent_t take_event(zip_ctx *ctx) {
@@ -242,10 +279,15 @@ FieldDev<FL> to_dev(const HostField &h) {
 // ------------------------------------------------------------------ commit dispatch
 template <int E, bool HASH, bool T2_LDS>
 int32_t launch_commit(zip_ctx *ctx, const CommitArgs &a, uint32_t threads) {
-    const size_t lds = 256 + (T2_LDS ? (size_t)a.cw * 12 + (size_t)a.row_len * 8 : 0);
+    // wave totals + E planes of (threads + 32/E) slots of 12 bytes + the witness row
+    const size_t lds = 256 + (T2_LDS ? (size_t)E * (threads + 32 / E) * 12 + (size_t)a.row_len * 8 : 0);
     auto kern = raa_commit_kernel<E, HASH, T2_LDS>;
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static size_t lds_attr = 0;  // per instantiation
+    if (lds > lds_attr) {
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_attr = lds;
+    }
     LaunchTimer t(ctx, HASH ? "raa_commit_kernel" : "raa_encode_kernel");
     hipLaunchKernelGGL(kern, dim3(ctx->rows_local), dim3(threads), lds, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
@@ -345,8 +387,9 @@ struct CombineOut {
     uint8_t *row_be = nullptr;      // device
 };
 
+// coeffs_d / q0_d: DEVICE pointers (already staged)
 template <int FL>
-int32_t run_combine_fl(zip_ctx *ctx, const int64_t *evals_d, const int64_t *coeffs_h, const uint64_t *q0_h,
+int32_t run_combine_fl(zip_ctx *ctx, const int64_t *evals_d, const int64_t *coeffs_dv, const uint64_t *q0_dv,
                        const HostField *hf, bool do_int, bool do_field, const CombineOut &out) {
     const uint32_t R = ctx->rows_local, C = ctx->p.row_len;
     const uint32_t bx = (C + 255) / 256;
@@ -356,7 +399,7 @@ int32_t run_combine_fl(zip_ctx *ctx, const int64_t *evals_d, const int64_t *coef
     const uint32_t rpc = (R + chunks - 1) / chunks;
     chunks = (R + rpc - 1) / rpc;
 
-    Scratch coeffs_d(ctx), q0_d(ctx), pint(ctx), pa(ctx), pb(ctx);
+    Scratch pint(ctx), pa(ctx), pb(ctx);
     int32_t rc;
     CombineArgs a{};
     a.evals = evals_d;
@@ -365,18 +408,14 @@ int32_t run_combine_fl(zip_ctx *ctx, const int64_t *evals_d, const int64_t *coef
     a.rows_per_chunk = rpc;
     a.quirk_mod = hf ? hf->quirk_mod : 0;
     if (do_int) {
-        if ((rc = coeffs_d.get((size_t)R * 8))) return rc;
         if ((rc = pint.get((size_t)chunks * C * 3 * 8))) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(coeffs_d.ptr, coeffs_h, (size_t)R * 8, hipMemcpyHostToDevice, ctx->stream));
-        a.coeffs = coeffs_d.as<int64_t>();
+        a.coeffs = coeffs_dv;
         a.part_int = pint.as<uint64_t>();
     }
     if (do_field) {
-        if ((rc = q0_d.get((size_t)R * FL * 8))) return rc;
         if ((rc = pa.get((size_t)chunks * C * (FL + 2) * 8))) return rc;
         if ((rc = pb.get((size_t)chunks * C * (FL + 1) * 8))) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(q0_d.ptr, q0_h, (size_t)R * FL * 8, hipMemcpyHostToDevice, ctx->stream));
-        a.q0 = q0_d.as<uint64_t>();
+        a.q0 = q0_dv;
         a.part_a = pa.as<uint64_t>();
         a.part_b = pb.as<uint64_t>();
     }
@@ -414,37 +453,35 @@ int32_t run_combine_fl(zip_ctx *ctx, const int64_t *evals_d, const int64_t *coef
             hipLaunchKernelGGL((combine_finalize_kernel<FL, false, true>), grid, block, 0, ctx->stream, fa, fd);
         HIP_TRY(ctx, hipGetLastError());
     }
-    // the H2D copies above read pageable host memory; make sure they are done before returning
-    // control to a caller that may free coeffs / q0 (hipMemcpyAsync from pageable memory is
-    // staged, but be explicit)
     return ZIP_OK;
 }
 
-int32_t run_combine(zip_ctx *ctx, const int64_t *evals_d, const int64_t *coeffs_h, const uint64_t *q0_h,
+int32_t run_combine(zip_ctx *ctx, const int64_t *evals_d, const int64_t *coeffs_dv, const uint64_t *q0_dv,
                     const HostField *hf, bool do_int, bool do_field, const CombineOut &out) {
     const uint32_t fl = hf ? hf->fl : 4;
     switch (fl) {
-        case 2: return run_combine_fl<2>(ctx, evals_d, coeffs_h, q0_h, hf, do_int, do_field, out);
-        case 3: return run_combine_fl<3>(ctx, evals_d, coeffs_h, q0_h, hf, do_int, do_field, out);
-        default: return run_combine_fl<4>(ctx, evals_d, coeffs_h, q0_h, hf, do_int, do_field, out);
+        case 2: return run_combine_fl<2>(ctx, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out);
+        case 3: return run_combine_fl<3>(ctx, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out);
+        default: return run_combine_fl<4>(ctx, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out);
     }
 }
 
-int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_h, uint32_t n_cols, uint8_t *out_d) {
-    zip_ctx *ctx = c->ctx;
-    if (n_cols == 0) return ZIP_OK;
+int32_t check_cols(zip_ctx *ctx, const uint32_t *cols_h, uint32_t n_cols) {
     for (uint32_t i = 0; i < n_cols; i++)
         if (cols_h[i] >= ctx->p.codeword_len)
             return fail(ctx, ZIP_ERR_INVALID_PARAM, "column index %u out of range (codeword_len %u)", cols_h[i],
                         ctx->p.codeword_len);
-    Scratch cols_d(ctx);
-    int32_t rc;
-    if ((rc = cols_d.get((size_t)n_cols * 4))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(cols_d.ptr, cols_h, (size_t)n_cols * 4, hipMemcpyHostToDevice, ctx->stream));
+    return ZIP_OK;
+}
+
+// cols_dv: DEVICE pointer (already staged)
+int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d) {
+    zip_ctx *ctx = c->ctx;
+    if (n_cols == 0) return ZIP_OK;
     OpenColsArgs a{};
     a.rows = c->rows;
     a.layers = reinterpret_cast<const uint64_t *>(c->layers);
-    a.cols = cols_d.as<uint32_t>();
+    a.cols = cols_dv;
     a.out = out_d;
     a.num_rows = ctx->rows_local;
     a.cw = ctx->p.codeword_len;
@@ -576,6 +613,7 @@ void zip_ctx_destroy(zip_ctx *ctx) {
         (void)hipEventDestroy(pe.stop);
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->stage_h) (void)hipHostFree(ctx->stage_h);
     if (ctx->perm1_d) (void)hipFree(ctx->perm1_d);
     if (ctx->perm2_d) (void)hipFree(ctx->perm2_d);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -748,7 +786,15 @@ int32_t zip_open_testing(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_
         if ((rc = res.get(bytes))) return rc;
         o.uprime = res.as<uint64_t>();
     }
-    if ((rc = run_combine(ctx, evals_d, coeffs, nullptr, nullptr, true, false, o))) return rc;
+    Scratch small(ctx);
+    SmallInputs si;
+    si.src[0] = coeffs;
+    si.bytes[0] = (size_t)ctx->rows_local * 8;
+    unsigned char *sb;
+    if ((rc = stage_small(ctx, si, small, &sb))) return rc;
+    if ((rc = run_combine(ctx, evals_d, reinterpret_cast<const int64_t *>(sb + si.off[0]), nullptr, nullptr, true,
+                          false, o)))
+        return rc;
     if (out_kind == ZIP_MEM_HOST) return deliver(ctx, uprime_out, ZIP_MEM_HOST, o.uprime, bytes);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // coeffs were read from host memory
     return ZIP_OK;
@@ -768,9 +814,16 @@ int32_t zip_open_columns(zip_commitment *c, const uint32_t *cols, uint32_t n_col
         if ((rc = res.get(bytes))) return rc;
         out_d = res.as<uint8_t>();
     }
-    if ((rc = run_open_columns(c, cols, n_cols, out_d))) return rc;
+    if ((rc = check_cols(ctx, cols, n_cols))) return rc;
+    Scratch small(ctx);
+    SmallInputs si;
+    si.src[0] = cols;
+    si.bytes[0] = (size_t)n_cols * 4;
+    unsigned char *sb;
+    if ((rc = stage_small(ctx, si, small, &sb))) return rc;
+    if ((rc = run_open_columns(c, reinterpret_cast<const uint32_t *>(sb), n_cols, out_d))) return rc;
     if (out_kind == ZIP_MEM_HOST) return deliver(ctx, wire_out, ZIP_MEM_HOST, out_d, bytes);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // cols were read from host memory
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the pinned staging buffer is free again
     return ZIP_OK;
 }
 
@@ -795,7 +848,15 @@ int32_t zip_open_eval(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_kin
         o.row_limbs = res.as<uint64_t>();
     }
     // one row: the evaluation row is map_to_field(evals) = 1_mont * w (open_z.rs:84-88)
-    if ((rc = run_combine(ctx, evals_d, nullptr, single ? hf.r : q0_mont, &hf, false, true, o))) return rc;
+    Scratch small(ctx);
+    SmallInputs si;
+    si.src[1] = single ? hf.r : q0_mont;
+    si.bytes[1] = (size_t)ctx->rows_local * hf.fl * 8;
+    unsigned char *sb;
+    if ((rc = stage_small(ctx, si, small, &sb))) return rc;
+    if ((rc = run_combine(ctx, evals_d, nullptr, reinterpret_cast<const uint64_t *>(sb + si.off[1]), &hf, false, true,
+                          o)))
+        return rc;
     if (out_kind == ZIP_MEM_HOST) return deliver(ctx, row_out, ZIP_MEM_HOST, o.row_limbs, bytes);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ZIP_OK;
@@ -842,8 +903,24 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
     CombineOut o{};
     o.uprime = single ? nullptr : reinterpret_cast<uint64_t *>(out_d);
     o.row_be = out_d + u_bytes + col_bytes;
-    if ((rc = run_combine(ctx, evals_d, coeffs, single ? hf.r : q0_mont, &hf, !single, true, o))) return rc;
-    if ((rc = run_open_columns(c, cols, n_cols, out_d + u_bytes))) return rc;
+    if ((rc = check_cols(ctx, cols, n_cols))) return rc;
+    Scratch small(ctx);
+    SmallInputs si;
+    if (!single) {
+        si.src[0] = coeffs;
+        si.bytes[0] = (size_t)ctx->rows_local * 8;
+    }
+    si.src[1] = single ? hf.r : q0_mont;
+    si.bytes[1] = (size_t)ctx->rows_local * hf.fl * 8;
+    si.src[2] = cols;
+    si.bytes[2] = (size_t)n_cols * 4;
+    unsigned char *sb;
+    if ((rc = stage_small(ctx, si, small, &sb))) return rc;
+    if ((rc = run_combine(ctx, evals_d, reinterpret_cast<const int64_t *>(sb + si.off[0]),
+                          reinterpret_cast<const uint64_t *>(sb + si.off[1]), &hf, !single, true, o)))
+        return rc;
+    if ((rc = run_open_columns(c, reinterpret_cast<const uint32_t *>(sb + si.off[2]), n_cols, out_d + u_bytes)))
+        return rc;
     if (out_kind == ZIP_MEM_HOST) return deliver(ctx, proof_out, ZIP_MEM_HOST, out_d, total);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // small host inputs (coeffs, cols, q0) were consumed
     return ZIP_OK;
