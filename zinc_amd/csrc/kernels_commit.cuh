@@ -30,9 +30,16 @@ struct CommitArgs {
     const uint32_t *perm2;
     uint64_t *rows;
     uint32_t *layers;  // 8 words per hash
+    uint32_t *roots;   // [rows][8]
     uint32_t row_len;
     uint32_t cw;
     uint32_t nact;  // active threads per workgroup = cw / E
+    uint32_t num_rows;          // rows of this ctx (the kernel is persistent: row = blockIdx.x + i * gridDim.x)
+    uint32_t rounds_per_chunk;  // a chunk = this many consecutive rounds of gridDim.x rows
+    uint32_t *chunk_done;       // [chunks] arrival counters, or null
+#ifdef ZIPK_DEBUG_STAMPS
+    unsigned long long *stamps;  // tools/ubench_pipeline.hip: [chunk][workgroup] wall-clock of each arrival
+#endif
 };
 
 __device__ __forceinline__ i128 shfl_up_i96(i128 x, int off) {
@@ -44,8 +51,16 @@ __device__ __forceinline__ i128 shfl_up_i96(i128 x, int off) {
     return (i128)(((u128)(uint64_t)hi << 64) | ((u128)d1 << 32) | d0);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter (s_waitcnt vmcnt(0)), i.e. waits for every outstanding global STORE of the wave to be
+// acknowledged; between the passes of a row only LDS data is exchanged, and waiting on the row
+// and hash stores there makes the kernel sensitive to memory latency for nothing.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Exclusive prefix over the workgroup of one (<= 96-bit signed) value per thread.
-// wave_tot: LDS scratch of >= 16 entries.  Contains two barriers.
+// wave_tot: LDS scratch of >= 16 entries.  Contains two (LDS-only) barriers.
 __device__ __forceinline__ i128 block_exclusive_scan_i96(i128 total, i128 *wave_tot) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     i128 x = total;
@@ -55,10 +70,10 @@ __device__ __forceinline__ i128 block_exclusive_scan_i96(i128 total, i128 *wave_
         if (lane >= off) x += y;
     }
     if (lane == 63) wave_tot[wid] = x;
-    __syncthreads();
+    lds_barrier();
     i128 base = 0;
     for (int w = 0; w < wid; w++) base += wave_tot[w];
-    __syncthreads();
+    lds_barrier();
     return base + (x - total);
 }
 
@@ -111,6 +126,7 @@ struct CommitLeaves {
     }
 };
 
+
 // Strided ownership for the output phase: at step e lane t owns codeword entry
 // j = e*T + t, so the 32-byte row entries, leaf hashes and nodes that a wave stores in one
 // instruction are adjacent in memory (4 lanes per 128-byte line instead of one lane per
@@ -124,19 +140,34 @@ struct StridedLeaves {
     uint32_t *tree;
     uint32_t cw, T, tid;
     template <int E0>
-    __device__ __forceinline__ void leaf(uint32_t (&h)[8]) {
+    __device__ __forceinline__ void store_row() {
         const uint32_t j = E0 * T + tid;
         const uint32_t s = (uint32_t)((int32_t)w2[E0] >> 31);
         uint4 *o = reinterpret_cast<uint4 *>(out_row + (size_t)j * 4);
         o[0] = make_uint4(w0[E0], w1[E0], w2[E0], s);  // sign extension to Int<4>
         o[1] = make_uint4(s, s, s, s);
-        blake3_leaf_sext96(w0[E0], w1[E0], w2[E0], h);
-        store_hash(tree + (size_t)j * 8, h);
     }
-    __device__ __forceinline__ void store(int lvl, uint32_t e, const uint32_t (&h)[8]) {
-        store_hash(tree + ((size_t)level_off(cw, lvl) + ((e * T + tid) >> lvl)) * 8, h);
+    template <int E0>
+    __device__ __forceinline__ void leaf(uint32_t (&h)[8]) {
+        store_row<E0>();
+        blake3_leaf_sext96(w0[E0], w1[E0], w2[E0], h);
+        store_hash(tree + (size_t)(E0 * T + tid) * 8, h);
+    }
+    // node of local level LVL computed by this lane: step E0 + (tid mod 2^LVL)
+    template <int LVL, int E0>
+    __device__ __forceinline__ void store(const uint32_t (&h)[8]) {
+        const uint32_t e = E0 + (tid & ((1u << LVL) - 1u));
+        store_hash(tree + ((size_t)level_off(cw, LVL) + ((e * T + tid) >> LVL)) * 8, h);
     }
 };
+
+template <int E, int E0>
+__device__ __forceinline__ void store_rows_only(StridedLeaves<E> &src) {
+    if constexpr (E0 < E) {
+        src.template store_row<E0>();
+        store_rows_only<E, E0 + 1>(src);
+    }
+}
 
 template <int LVL, int E0, class Src>
 __device__ __forceinline__ void bfly_hash(Src &src, uint32_t (&h)[8]) {
@@ -155,14 +186,25 @@ __device__ __forceinline__ void bfly_hash(Src &src, uint32_t (&h)[8]) {
             m[8 + i] = up ? B[i] : rcv;  // right child
         }
         blake3_block(m, 64u, h);
-        src.store(LVL, E0 + (src.tid & ((1u << LVL) - 1u)), h);
+        src.template store<LVL, E0>(h);
     }
 }
 
-// One workgroup per witness row; thread t owns the E consecutive codeword entries
-// [t*E, t*E+E).  Values never exceed 64 + 2*log2(cw) + 1 <= 96 bits (width
-// assertion src/zip/code_raa.rs:53-72), so scans run on i128 lanes and the 256-bit
-// result is the sign extension.
+// Returns 0 in a way the optimiser cannot see through.  Adding it to the per-row index
+// arithmetic keeps loop-invariant code motion from hoisting ~50 registers of permutation
+// indices / addresses out of the persistent row loop (which pushed the kernel to 128 VGPRs,
+// i.e. a full register file and no co-residency).
+__device__ __forceinline__ uint32_t opaque_zero(uint32_t dep) {
+    uint32_t z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z) : "s"(dep));
+    return z;
+}
+
+// Persistent commit kernel: gridDim.x workgroups (one per CU), workgroup g encodes and
+// hashes rows g, g + G, g + 2G, ...  Within a row thread t owns the E consecutive codeword
+// entries [t*E, t*E+E) during the two scans.  Values never exceed 64 + 2*log2(cw) + 1 <= 96
+// bits (width assertion src/zip/code_raa.rs:53-72), so the scans run on i128 lanes and the
+// 256-bit result is the sign extension.
 //   T2_LDS = true : witness row and the intermediate codeword t2 live in LDS
 //                   (cw*12 + row_len*8 bytes; up to cw = 8192).
 //   T2_LDS = false: t2 is parked in the (not yet written) output row in HBM/L2
@@ -170,147 +212,289 @@ __device__ __forceinline__ void bfly_hash(Src &src, uint32_t (&h)[8]) {
 // In LDS, entry j sits at slot (j % E) * (T + 32/E) + j / E: the thread-contiguous writes
 // of a wave are bank-conflict free, and so are the strided reads (entry e*T + t) of the
 // output phase; the pi2 gather is random either way.
+//
+// Being resident on every CU for the whole commit, the kernel is never displaced by the
+// consumers that run beside it on other streams (upper Merkle levels, column gather): those
+// only ever get the wave slots / LDS this kernel leaves free.  Rows are grouped into chunks of
+// `rounds_per_chunk` rounds; when a workgroup has finished its rows of a chunk it publishes
+// them (agent-scope release) and bumps chunk_done[chunk]; a chunk is complete when every
+// workgroup that owns rows in it has done so.
+//
+// Register budget: 1024 threads are 4 waves per SIMD; capping the kernel at 512/5 -> 96 VGPRs
+// (second __launch_bounds__ argument = waves per SIMD) leaves a quarter of every SIMD register
+// file to the consumer kernels.  At 128 VGPRs the file is full and nothing can co-reside
+// (measured: a probe kernel on another stream then only runs when this kernel ends).
 template <int E, bool HASH, bool T2_LDS>
-__global__ void __launch_bounds__(1024) raa_commit_kernel(CommitArgs a) {
+__global__ void __launch_bounds__(1024, (E <= 8 ? 5 : 4)) raa_commit_kernel(CommitArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int LOGE = (E == 1) ? 0 : (E == 2) ? 1 : (E == 4) ? 2 : (E == 8) ? 3 : 4;
     static_assert((1 << LOGE) == E, "E must be a power of two <= 16");
 
-    const uint32_t tid = threadIdx.x, T = blockDim.x;
+    const uint32_t tid0 = threadIdx.x, T = blockDim.x;
     constexpr uint32_t PAD = 32 / E;
     const uint32_t PS = T + PAD;  // plane stride (slots)
-    const uint32_t row = blockIdx.x;
     const uint32_t cw = a.cw, row_len = a.row_len;
-    const bool active = tid < a.nact;
-    const uint32_t j0 = tid * E;
+    const bool active = tid0 < a.nact;
 
     i128 *wave_tot = reinterpret_cast<i128 *>(smem);                  // 16 entries
     uint64_t *t2lo = reinterpret_cast<uint64_t *>(smem + 256);         // E planes of PS slots
     uint32_t *t2hi = reinterpret_cast<uint32_t *>(t2lo + (T2_LDS ? E * PS : 0));
     int64_t *rowbuf = reinterpret_cast<int64_t *>(t2hi + (T2_LDS ? E * PS : 0));
 
-    const int64_t *in = a.evals + (size_t)row * row_len;
-    uint64_t *out_row = a.rows + (size_t)row * cw * 4;
-    u128 *t2g = reinterpret_cast<u128 *>(out_row);  // T2_LDS == false: first half of the output row
-
+    // Row-invariant state kept in registers so that no global load sits on the per-row critical
+    // path: the thread's permutation indices (packed: pi1 source index | pi2 LDS slot << 16) ...
+    uint32_t pidx[E];
     if (T2_LDS) {
-        for (uint32_t i = tid; i < row_len; i += T) rowbuf[i] = in[i];
-        __syncthreads();
-    }
-
-    i128 v[E];
-    // ---- pass 1: repeat + permute(pi1) + accumulate ----------------------------
-    if (active) {
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            const uint32_t src = a.perm1[j0 + e] & (row_len - 1);  // repeat: t0[j] = row[j mod row_len]
-            v[e] = (i128)(T2_LDS ? rowbuf[src] : in[src]);
+            uint32_t v1 = 0, v2 = 0;
+            if (active) {
+                v1 = a.perm1[tid0 * E + e] & (row_len - 1);  // repeat: t0[j] = row[j mod row_len]
+                const uint32_t p2 = a.perm2[tid0 * E + e];
+                v2 = (p2 & (E - 1)) * PS + (p2 >> LOGE);
+            }
+            pidx[e] = v1 | (v2 << 16);
         }
-#pragma unroll
-        for (int e = 1; e < E; e++) v[e] += v[e - 1];
-    } else {
-#pragma unroll
-        for (int e = 0; e < E; e++) v[e] = 0;
     }
-    {
-        const i128 pre = block_exclusive_scan_i96(v[E - 1], wave_tot);
+    // ... and the NEXT witness row, fetched while the current one is being hashed (rep = 2
+    // geometry: row_len == NPF * blockDim; anything else takes the direct path).
+    constexpr int NPF = (E >= 2) ? E / 2 : 1;
+    const bool prefetch = T2_LDS && row_len == NPF * T;
+    int64_t nxt[NPF];
+
+#ifdef ZIPK_DEBUG_STAMPS
+    unsigned long long ph_a = 0, ph_b = 0, ph_c = 0, ph_t;
+#define ZIPK_PH(acc) do { const unsigned long long now_ = wall_clock64(); acc += now_ - ph_t; ph_t = now_; } while (0)
+#else
+#define ZIPK_PH(acc) do { } while (0)
+#endif
+    uint32_t round = 0;
+    for (uint32_t row = blockIdx.x; row < a.num_rows; row += gridDim.x, round++) {
+#ifdef ZIPK_DEBUG_STAMPS
+        ph_t = wall_clock64();
+#endif
+        const uint32_t z = opaque_zero(row);
+        const uint32_t tid = tid0 + z, j0 = tid * E;
+        const int64_t *in = a.evals + (size_t)row * row_len;
+        uint64_t *out_row = a.rows + (size_t)row * cw * 4;
+        u128 *t2g = reinterpret_cast<u128 *>(out_row);  // T2_LDS == false: first half of the output row
+
+        if (T2_LDS && !(prefetch && round)) {
+            if (round) lds_barrier();  // the previous row's LDS image has been consumed
+            for (uint32_t i = tid; i < row_len; i += T) rowbuf[i] = in[i];
+            lds_barrier();
+        }
+
+        i128 v[E];
+        // ---- pass 1: repeat + permute(pi1) + accumulate ------------------------
         if (active) {
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                v[e] += pre;
                 if (T2_LDS) {
-                    const uint32_t slot = e * PS + tid;
-                    t2lo[slot] = (uint64_t)v[e];
-                    t2hi[slot] = (uint32_t)((u128)v[e] >> 64);
+                    v[e] = (i128)rowbuf[pidx[e] & 0xFFFFu];
                 } else {
-                    t2g[j0 + e] = (u128)v[e];
+                    const uint32_t src = a.perm1[j0 + e] & (row_len - 1);
+                    v[e] = (i128)in[src];
+                }
+            }
+#pragma unroll
+            for (int e = 1; e < E; e++) v[e] += v[e - 1];
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; e++) v[e] = 0;
+        }
+        {
+            const i128 pre = block_exclusive_scan_i96(v[E - 1], wave_tot);
+            if (active) {
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    v[e] += pre;
+                    if (T2_LDS) {
+                        const uint32_t slot = e * PS + tid;
+                        t2lo[slot] = (uint64_t)v[e];
+                        t2hi[slot] = (uint32_t)((u128)v[e] >> 64);
+                    } else {
+                        t2g[j0 + e] = (u128)v[e];
+                    }
                 }
             }
         }
-    }
-    __syncthreads();
-    // ---- pass 2: permute(pi2) + accumulate -------------------------------------
-    if (active) {
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            const uint32_t src = a.perm2[j0 + e];
-            if (T2_LDS) {
-                const uint32_t slot = (src & (E - 1)) * PS + (src >> LOGE);
-                const uint64_t lo = t2lo[slot];
-                const int64_t hi = (int64_t)(int32_t)t2hi[slot];
-                v[e] = (i128)(((u128)(uint64_t)hi << 64) | lo);
-            } else {
-                v[e] = (i128)t2g[src];
-            }
-        }
-#pragma unroll
-        for (int e = 1; e < E; e++) v[e] += v[e - 1];
-    }
-    {
-        // the barriers inside also order the t2 reads above before the row stores below
-        const i128 pre = block_exclusive_scan_i96(v[E - 1], wave_tot);
-#pragma unroll
-        for (int e = 0; e < E; e++) v[e] += pre;
-    }
-    if (T2_LDS) {
-        // ---- transpose to strided ownership through LDS, then rows + hashes ----------
-        // (the second barrier inside the scan above already ordered every pi2 gather of t2
-        // before these writes)
+        if (T2_LDS) lds_barrier(); else __syncthreads();  // the global t2 needs the full fence
+        // ---- pass 2: permute(pi2) + accumulate ---------------------------------
         if (active) {
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const uint32_t slot = e * PS + tid;
-                t2lo[slot] = (uint64_t)v[e];
-                t2hi[slot] = (uint32_t)((u128)v[e] >> 64);
+                if (T2_LDS) {
+                    const uint32_t slot = pidx[e] >> 16;
+                    const uint64_t lo = t2lo[slot];
+                    const int64_t hi = (int64_t)(int32_t)t2hi[slot];
+                    v[e] = (i128)(((u128)(uint64_t)hi << 64) | lo);
+                } else {
+                    v[e] = (i128)t2g[a.perm2[j0 + e]];
+                }
             }
-        }
-        __syncthreads();
-        if (!active) return;
-        StridedLeaves<E> src;
-        src.out_row = out_row;
-        src.tree = HASH ? a.layers + (size_t)row * (2u * cw) * 8 : nullptr;
-        src.cw = cw;
-        src.T = a.nact;
-        src.tid = tid;
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const uint32_t j = e * a.nact + tid;
-            const uint32_t slot = (j & (E - 1)) * PS + (j >> LOGE);
-            const uint64_t lo = t2lo[slot];
-            src.w0[e] = (uint32_t)lo;
-            src.w1[e] = (uint32_t)(lo >> 32);
-            src.w2[e] = t2hi[slot];
+            for (int e = 1; e < E; e++) v[e] += v[e - 1];
         }
-        if (HASH) {
-            uint32_t top[8];
-            bfly_hash<LOGE, 0>(src, top);
-        } else {
+        {
+            // the barriers inside also order the t2 reads above before the stores below
+            const i128 pre = block_exclusive_scan_i96(v[E - 1], wave_tot);
+#pragma unroll
+            for (int e = 0; e < E; e++) v[e] += pre;
+        }
+        if (!T2_LDS) __syncthreads();  // every lane has read its t2 entries before the row is overwritten
+
+        const bool has_next = row + gridDim.x < a.num_rows;
+        if (T2_LDS) {
+            // ---- transpose to strided ownership through LDS, then rows + hashes ------
+            if (active) {
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const uint32_t slot = e * PS + tid;
+                    t2lo[slot] = (uint64_t)v[e];
+                    t2hi[slot] = (uint32_t)((u128)v[e] >> 64);
+                }
+            }
+            lds_barrier();
+            if (prefetch && has_next) {  // in flight during the whole hash phase
+                const int64_t *nin = a.evals + (size_t)(row + gridDim.x) * row_len;
+#pragma unroll
+                for (int k = 0; k < NPF; k++) nxt[k] = nin[k * T + tid];
+            }
+            ZIPK_PH(ph_a);
+            if (active) {
+                StridedLeaves<E> src;
+                src.out_row = out_row;
+                src.tree = HASH ? a.layers + (size_t)row * (2u * cw) * 8 : nullptr;
+                src.cw = cw;
+                src.T = a.nact;
+                src.tid = tid;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const uint32_t j = e * a.nact + tid;
+                    const uint32_t slot = (j & (E - 1)) * PS + (j >> LOGE);
+                    const uint64_t lo = t2lo[slot];
+                    src.w0[e] = (uint32_t)lo;
+                    src.w1[e] = (uint32_t)(lo >> 32);
+                    src.w2[e] = t2hi[slot];
+                }
+                if (HASH) {
+                    uint32_t top[8];
+                    bfly_hash<LOGE, 0>(src, top);
+                } else {
+                    store_rows_only<E, 0>(src);
+                }
+            }
+        } else if (active) {
+            // ---- thread-contiguous outputs (cw too large for the LDS transposition) -----
+            uint4 *orow = reinterpret_cast<uint4 *>(out_row + (size_t)j0 * 4);
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const uint32_t j = e * a.nact + tid;
-                const uint32_t sg = (uint32_t)((int32_t)src.w2[e] >> 31);
-                uint4 *o = reinterpret_cast<uint4 *>(out_row + (size_t)j * 4);
-                o[0] = make_uint4(src.w0[e], src.w1[e], src.w2[e], sg);
-                o[1] = make_uint4(sg, sg, sg, sg);
+                const uint32_t d0 = (uint32_t)v[e], d1 = (uint32_t)((u128)v[e] >> 32),
+                               d2 = (uint32_t)((u128)v[e] >> 64);
+                const uint32_t sg = (uint32_t)((int32_t)d2 >> 31);
+                orow[2 * e] = make_uint4(d0, d1, d2, sg);
+                orow[2 * e + 1] = make_uint4(sg, sg, sg, sg);
+            }
+            if (HASH) {
+                CommitLeaves<E> src{v, a.layers + (size_t)row * (2u * cw) * 8, cw, j0};
+                uint32_t top[8];
+                subtree_hash<LOGE, 0>(src, top);
             }
         }
-    } else {
-        if (!active) return;
-        // ---- thread-contiguous outputs (cw too large for the LDS transposition) -----
-        uint4 *orow = reinterpret_cast<uint4 *>(out_row + (size_t)j0 * 4);
+
+        ZIPK_PH(ph_b);
+        // ---- finish a chunk: upper Merkle levels of this workgroup's rows, then publish ------
+        const bool last = row + gridDim.x >= a.num_rows;
+        if (last || (round + 1) % a.rounds_per_chunk == 0) {
+            if (HASH) {
+                // Levels LOGE+1 .. depth of the rows this workgroup encoded in the chunk, level by
+                // level over all of them at once: the first levels keep every lane busy, and the
+                // serial tail (one node per row at the top) is paid once per chunk, not per row.
+                // The children were stored by this workgroup: a barrier makes them visible (one
+                // CU, one L1; the lines were never read before they were written).
+                const uint32_t first = (round / a.rounds_per_chunk) * a.rounds_per_chunk;
+                const uint32_t nrows_c = round - first + 1;
+                const uint32_t depth = 31u - __builtin_clz(cw);
+                __syncthreads();
+                for (uint32_t lvl = LOGE + 1; lvl <= depth; lvl++) {
+                    const uint32_t wshift = depth - lvl;  // log2(width of this level)
+                    const uint32_t total = nrows_c << wshift;
+                    for (uint32_t idx = tid; idx < total; idx += T) {
+                        const uint32_t ri = idx >> wshift, i = idx & ((1u << wshift) - 1u);
+                        const uint32_t r = blockIdx.x + (first + ri) * gridDim.x;
+                        uint32_t *tree = a.layers + (size_t)r * (2u * cw) * 8;
+                        const uint32_t *ch = tree + ((size_t)level_off(cw, lvl - 1) + 2u * i) * 8;
+                        uint32_t l[8], rr[8], h[8];
+                        load_hash(ch, l);
+                        load_hash(ch + 8, rr);
+                        blake3_node(l, rr, h);
+                        store_hash(tree + ((size_t)level_off(cw, lvl) + i) * 8, h);
+                        if (lvl == depth) store_hash(a.roots + (size_t)r * 8, h);
+                    }
+                    __syncthreads();
+                }
+                if (depth == 0 && tid == 0) {  // a one-leaf tree: the root is the leaf hash
+                    for (uint32_t ri = 0; ri < nrows_c; ri++) {
+                        const uint32_t r = blockIdx.x + (first + ri) * gridDim.x;
+                        uint32_t h[8];
+                        load_hash(a.layers + (size_t)r * (2u * cw) * 8, h);
+                        store_hash(a.roots + (size_t)r * 8, h);
+                    }
+                }
+            }
+            if (a.chunk_done) {
+                __syncthreads();  // every wave's stores are issued and waited for (vmcnt(0) + barrier)
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back has landed before the count moves
+                    __hip_atomic_fetch_add(&a.chunk_done[round / a.rounds_per_chunk], 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+#ifdef ZIPK_DEBUG_STAMPS
+                    a.stamps[(round / a.rounds_per_chunk) * gridDim.x + blockIdx.x] = wall_clock64();
+#endif
+                }
+            }
+        }
+        if (prefetch && has_next) {
+            // rowbuf was last read in pass 1 and every lane has finished with the planes: stage the
+            // prefetched row for the next iteration (which then starts straight in pass 1)
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const uint32_t d0 = (uint32_t)v[e], d1 = (uint32_t)((u128)v[e] >> 32),
-                           d2 = (uint32_t)((u128)v[e] >> 64);
-            const uint32_t sg = (uint32_t)((int32_t)d2 >> 31);
-            orow[2 * e] = make_uint4(d0, d1, d2, sg);
-            orow[2 * e + 1] = make_uint4(sg, sg, sg, sg);
+            for (int k = 0; k < NPF; k++) rowbuf[k * T + tid] = nxt[k];
+            lds_barrier();
         }
-        if (HASH) {
-            CommitLeaves<E> src{v, a.layers + (size_t)row * (2u * cw) * 8, cw, j0};
-            uint32_t top[8];
-            subtree_hash<LOGE, 0>(src, top);
+        ZIPK_PH(ph_c);
+    }
+#ifdef ZIPK_DEBUG_STAMPS
+    if (tid0 == 0 && a.stamps) {
+        unsigned long long *o = a.stamps + 64 * gridDim.x + 4 * blockIdx.x;
+        o[0] = ph_a; o[1] = ph_b; o[2] = ph_c;
+    }
+#endif
+}
+
+// One wave that parks a stream until `*counter >= target` (a chunk of the persistent commit
+// kernel is complete).  The spin is bounded: after `timeout_ticks` of the 100 MHz wall clock
+// it gives up and raises *timeout_flag, so a lost producer cannot hang the GPU.
+// The poll is an atomic read-modify-write (add 0): device-scope atomics execute at the memory
+// side, whereas a plain or sc1 load can keep hitting a stale copy of the line in this XCD's L2
+// for as long as the producer kernel runs (observed: the wait only ended at the producer's end).
+// (`zero` is a runtime 0: a literal would let the compiler fold the RMW back into a load.)
+__global__ void __launch_bounds__(64) wait_counter_kernel(uint32_t *counter, uint32_t target, uint32_t zero,
+                                                          uint32_t *timeout_flag, unsigned long long timeout_ticks) {
+    // Four older, always-ready hashing waves share this SIMD: without a priority bump this
+    // wave only gets issue slots when they drain (observed: the wait ended with the producer).
+    __builtin_amdgcn_s_setprio(3);
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_fetch_add(counter, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(64);
+            if (wall_clock64() - t0 > timeout_ticks) {
+                __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
 }
 

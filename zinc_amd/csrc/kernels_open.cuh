@@ -310,40 +310,88 @@ struct OpenColsArgs {
     const uint64_t *layers;  // [num_rows][2*cw][4]
     const uint32_t *cols;    // [n_cols] (device)
     uint8_t *out;            // wire stream of the openings
-    uint32_t num_rows, cw, depth, k_limbs, rows_per_block;
+    uint32_t num_rows, cw, depth, k_limbs;
+    uint32_t row_lo, row_hi;  // rows handled by this launch (one pipeline chunk)
+    uint32_t rows_per_block;  // even, or the launch has a single block row
+    uint32_t prio;            // s_setprio level of the gather waves (tuning knob)
 };
 
+// Grid (n_cols, row blocks): blocks that run together share a narrow band of rows, so the
+// upper tree levels of those rows are served from L2 / Infinity Cache while the leaf-level
+// lines stream from HBM once.
+// A path record (be64(depth) + depth sibling hashes) is only 8-byte aligned in the stream,
+// so a block first assembles the byte-exact image of its records in LDS from aligned
+// 16-byte loads (two lanes per 32-byte node -> one request), then streams the image out as
+// aligned 16-byte stores, 1 KiB per wave instruction.
+//
+// The kernel usually runs BESIDE the VALU-bound persistent commit kernel, so every vector
+// instruction it issues is taken from the hashing waves: each thread keeps one fixed
+// (level, half) role, and walking the rows is one pointer increment per 16-byte load -- no
+// divisions, no per-element address arithmetic.  SLOTS = lanes reserved per row
+// (2*depth + 1 rounded up to 32 or 64).
+template <int SLOTS>
 __global__ void __launch_bounds__(256) open_columns_kernel(OpenColsArgs a) {
+    extern __shared__ __align__(16) unsigned char img[];
+    constexpr uint32_t K = 4;               // Int<4> column values (checked by zip_ctx_create)
+    constexpr uint32_t RPP = 256 / SLOTS;   // rows per pass of the block
+    if (a.prio) __builtin_amdgcn_s_setprio(2);  // memory-bound: do not queue behind older hashing waves
     const uint32_t ci = blockIdx.x;
     const uint32_t col = a.cols[ci];
-    const uint32_t r0 = blockIdx.y * a.rows_per_block;
-    const uint32_t r1 = min(r0 + a.rows_per_block, a.num_rows);
-    const uint32_t K = a.k_limbs, d = a.depth;
-    const uint32_t rec_words = 1 + 4 * d;
-    const size_t col_bytes = (size_t)a.num_rows * (8 * K + 8 * rec_words);
-    uint64_t *vals = reinterpret_cast<uint64_t *>(a.out + (size_t)ci * col_bytes);
-    uint64_t *recs = vals + (size_t)a.num_rows * K;
+    const uint32_t d = a.depth, cw2 = 2u * a.cw;
+    const uint32_t rec_bytes = 8 + 32 * d;
+    const size_t col_bytes = (size_t)a.num_rows * (8 * K + rec_bytes);
+    uint8_t *base = a.out + (size_t)ci * col_bytes;
+    const uint32_t r0 = a.row_lo + blockIdx.y * a.rows_per_block;
+    const uint32_t r1 = min(r0 + a.rows_per_block, a.row_hi);
+    const uint32_t nrows = r1 - r0;
 
-    // column values: K words per row
-    for (uint32_t i = threadIdx.x; i < (r1 - r0) * K; i += blockDim.x) {
-        const uint32_t r = r0 + i / K, k = i % K;
-        vals[(size_t)r * K + k] = a.rows[((size_t)r * a.cw + col) * K + k];
-    }
-    // Merkle paths: one 64-lane wave per row record (rec_words <= 64 for depth <= 15)
-    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (uint32_t r = r0 + wid; r < r1; r += nw) {
-        const uint64_t *tree = a.layers + (size_t)r * (2u * a.cw) * 4;
-        for (uint32_t k = lane; k < rec_words; k += 64) {
-            uint64_t word;
-            if (k == 0) {
-                word = __builtin_bswap64((uint64_t)d);
-            } else {
-                const uint32_t lvl = (k - 1) >> 2, part = (k - 1) & 3;
-                const uint32_t off = 2u * a.cw - ((2u * a.cw) >> lvl);
-                word = tree[((size_t)off + ((col >> lvl) ^ 1u)) * 4 + part];
+    // ---- phase 1: gather sibling hashes into the LDS image ----
+    // lane role h < 2*depth: half (h & 1) of the level-(h >> 1) sibling (pcs/utils.rs:163-176);
+    // h == 2*depth: the be64(depth) length prefix (pcs_transcript.rs:200-203).
+    {
+        const uint32_t h = threadIdx.x & (SLOTS - 1), rsub = threadIdx.x / SLOTS;
+        const uint32_t lvl = h >> 1;
+        const uint32_t node = cw2 - (cw2 >> lvl) + ((col >> lvl) ^ 1u);
+        const uint64_t *src = a.layers + ((size_t)(r0 + rsub) * cw2 + node) * 4 + (h & 1) * 2;
+        unsigned char *dst = img + (size_t)rsub * rec_bytes + 8 + (size_t)h * 16;
+        const size_t src_step = (size_t)RPP * cw2 * 4;
+        const uint32_t dst_step = RPP * rec_bytes;
+        if (h < 2 * d) {
+#pragma unroll 4
+            for (uint32_t rr = rsub; rr < nrows; rr += RPP, src += src_step, dst += dst_step) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src);
+                reinterpret_cast<uint64_t *>(dst)[0] = v.x;
+                reinterpret_cast<uint64_t *>(dst)[1] = v.y;
             }
-            recs[(size_t)r * rec_words + k] = word;
+        } else if (h == 2 * d) {
+            const uint64_t hdr = __builtin_bswap64((uint64_t)d);
+            for (uint32_t rr = rsub; rr < nrows; rr += RPP)
+                *reinterpret_cast<uint64_t *>(img + (size_t)rr * rec_bytes) = hdr;
         }
+    }
+    // ---- column values: rows[r*cw + col], K limbs little-endian (open_z.rs:130-137) ----
+    {
+        const uint32_t half = threadIdx.x & 1, rsub = threadIdx.x >> 1;  // two 16-byte halves per value
+        if (rsub < nrows) {
+            const uint32_t r = r0 + rsub;
+            const ulonglong2 v =
+                *reinterpret_cast<const ulonglong2 *>(a.rows + ((size_t)r * a.cw + col) * K + half * 2);
+            *reinterpret_cast<ulonglong2 *>(base + (size_t)r * 8 * K + half * 16) = v;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: stream the image out ----
+    unsigned char *recs = base + (size_t)a.num_rows * 8 * K + (size_t)r0 * rec_bytes;
+    const uint32_t total = nrows * rec_bytes;
+    if ((reinterpret_cast<uintptr_t>(recs) & 15) == 0) {
+        const uint32_t n16 = total / 16;
+        for (uint32_t i = threadIdx.x; i < n16; i += 256)
+            reinterpret_cast<uint4 *>(recs)[i] = reinterpret_cast<const uint4 *>(img)[i];
+        if (threadIdx.x == 0 && (total & 15))
+            reinterpret_cast<uint64_t *>(recs)[n16 * 2] = reinterpret_cast<const uint64_t *>(img)[n16 * 2];
+    } else {
+        for (uint32_t i = threadIdx.x; i < total / 8; i += 256)
+            reinterpret_cast<uint64_t *>(recs)[i] = reinterpret_cast<const uint64_t *>(img)[i];
     }
 }
 

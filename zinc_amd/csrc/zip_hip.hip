@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -44,11 +45,20 @@ struct zip_ctx {
     uint32_t depth = 0;
     uint32_t rows_local = 0;
     int device = 0;
-    hipStream_t stream = nullptr;
+    // Three HIP streams form a row-chunked pipeline: `s_commit` runs the fused
+    // encode+hash kernel chunk by chunk, `s_upper` the upper Merkle levels of each finished
+    // chunk, and `stream` everything else (row combinations, column openings, copies).  Per-chunk
+    // events let the memory-bound column gather of chunk k overlap the VALU-bound hashing of
+    // chunk k+1.
+    hipStream_t stream = nullptr, s_commit = nullptr, s_upper = nullptr, s_aux = nullptr;
+    uint32_t n_chunks = 1;
+    uint32_t num_cus = 256;
+    uint32_t *timeout_flag_h = nullptr, *timeout_flag_d = nullptr;  // pinned: a pipeline wait gave up
+    std::vector<hipEvent_t> dep_event_pool;  // hipEventDisableTiming
     uint32_t *perm1_d = nullptr, *perm2_d = nullptr;
     // pinned host staging for the small per-call inputs (coeffs, q0, column indices): one
     // truly asynchronous H2D copy instead of several pageable (blocking, staged) ones
-    unsigned char *stage_h = nullptr;
+    unsigned char *pinned_base = nullptr, *stage_h = nullptr, *stage_big = nullptr;
     size_t stage_cap = 0;
     std::string last_error;
     // caching allocator: exact-size free lists
@@ -70,6 +80,13 @@ struct zip_commitment {
     uint32_t *roots = nullptr;   // [rows_local][8] or null
     int64_t *evals = nullptr;    // device copy owned by the handle when the witness came from the host
     size_t rows_bytes = 0, layers_bytes = 0, roots_bytes = 0, evals_bytes = 0;
+    // Pipeline state of the persistent commit kernel that produces this handle: chunk k = rows
+    // [bounds[k], bounds[k+1]) is complete (rows, trees, roots) once chunk_done[k] == expected[k].
+    std::vector<uint32_t> bounds, expected;
+    uint32_t *chunk_done = nullptr;  // device arrival counters
+    hipEvent_t zeroed = nullptr;     // counters reset (consumers must not look at stale values)
+    hipEvent_t done = nullptr;       // whole commit finished
+    std::vector<hipEvent_t> aux;     // other events owned by the handle, recycled with it
 };
 
 namespace {
@@ -154,7 +171,8 @@ int32_t stage_small(zip_ctx *ctx, SmallInputs &in, Scratch &dev, unsigned char *
     }
     if (total == 0) { *base = nullptr; return ZIP_OK; }
     if (total > ctx->stage_cap) {
-        if (ctx->stage_h) (void)hipHostFree(ctx->stage_h);
+        if (ctx->stage_big) (void)hipHostFree(ctx->stage_big);
+    if (ctx->pinned_base) (void)hipHostFree(ctx->pinned_base);
         ctx->stage_h = nullptr;
         ctx->stage_cap = 0;
         size_t cap = total < (1u << 20) ? (1u << 20) : total;
@@ -185,21 +203,40 @@ hipEvent_t take_event(zip_ctx *ctx) {
 
 struct LaunchTimer {
     zip_ctx *ctx;
+    hipStream_t st;
     PendingEvent pe{};
     bool on;
-    LaunchTimer(zip_ctx *c, const char *name) : ctx(c), on(c->profiling) {
+    LaunchTimer(zip_ctx *c, const char *name, hipStream_t stream = nullptr)
+        : ctx(c), st(stream ? stream : c->stream), on(c->profiling) {
         if (!on) return;
         pe.name = name;
         pe.start = take_event(ctx);
         pe.stop = take_event(ctx);
-        (void)hipEventRecord(pe.start, ctx->stream);
+        (void)hipEventRecord(pe.start, st);
     }
     ~LaunchTimer() {
         if (!on) return;
-        (void)hipEventRecord(pe.stop, ctx->stream);
+        (void)hipEventRecord(pe.stop, st);
         ctx->pending.push_back(pe);
     }
 };
+
+hipEvent_t take_dep_event(zip_ctx *ctx) {
+    if (!ctx->dep_event_pool.empty()) {
+        hipEvent_t e = ctx->dep_event_pool.back();
+        ctx->dep_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    return e;
+}
+
+// Orders `stream` after the whole commit that produces `c`.
+int32_t wait_ready(zip_commitment *c, hipStream_t stream) {
+    if (c->done) HIP_TRY(c->ctx, hipStreamWaitEvent(stream, c->done, 0));
+    return ZIP_OK;
+}
 
 // ------------------------------------------------------------------ field setup
 struct HostField {
@@ -277,8 +314,9 @@ FieldDev<FL> to_dev(const HostField &h) {
 }
 
 // ------------------------------------------------------------------ commit dispatch
+// Persistent launch: as many workgroups as stay resident together (at most one per row).
 template <int E, bool HASH, bool T2_LDS>
-int32_t launch_commit(zip_ctx *ctx, const CommitArgs &a, uint32_t threads) {
+int32_t launch_commit(zip_ctx *ctx, const CommitArgs &a, uint32_t threads, uint32_t grid, hipStream_t st) {
     // wave totals + E planes of (threads + 32/E) slots of 12 bytes + the witness row
     const size_t lds = 256 + (T2_LDS ? (size_t)E * (threads + 32 / E) * 12 + (size_t)a.row_len * 8 : 0);
     auto kern = raa_commit_kernel<E, HASH, T2_LDS>;
@@ -288,59 +326,67 @@ int32_t launch_commit(zip_ctx *ctx, const CommitArgs &a, uint32_t threads) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_attr = lds;
     }
-    LaunchTimer t(ctx, HASH ? "raa_commit_kernel" : "raa_encode_kernel");
-    hipLaunchKernelGGL(kern, dim3(ctx->rows_local), dim3(threads), lds, ctx->stream, a);
+    LaunchTimer t(ctx, HASH ? "raa_commit_kernel" : "raa_encode_kernel", st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
     HIP_TRY(ctx, hipGetLastError());
     return ZIP_OK;
 }
 
+struct CommitGeom {
+    uint32_t e, threads, levels_done;
+    bool t2_lds;
+    size_t lds;
+};
+CommitGeom commit_geom(uint32_t cw, uint32_t row_len) {
+    CommitGeom g{};
+    if (cw == 16384) { g.e = 16; g.threads = 1024; g.levels_done = 4; g.t2_lds = false; }
+    else if (cw >= 512) { g.e = 8; g.threads = cw / 8; g.levels_done = 3; g.t2_lds = true; }
+    else if (cw == 256) { g.e = 4; g.threads = 64; g.levels_done = 2; g.t2_lds = true; }
+    else if (cw == 128) { g.e = 2; g.threads = 64; g.levels_done = 1; g.t2_lds = true; }
+    else { g.e = 1; g.threads = 64; g.levels_done = 0; g.t2_lds = true; }  // cw <= 64: one entry per lane
+    g.lds = 256 + (g.t2_lds ? (size_t)g.e * (g.threads + 32 / g.e) * 12 + (size_t)row_len * 8 : 0);
+    return g;
+}
+// resident workgroups per CU of the commit kernel (threads and LDS)
+uint32_t commit_wgs_per_cu(const CommitGeom &g) {
+    uint32_t by_threads = 2048 / g.threads, by_lds = (uint32_t)((160u * 1024u) / g.lds);
+    uint32_t k = by_threads < by_lds ? by_threads : by_lds;
+    if (k > 8) k = 8;
+    return k ? k : 1;
+}
+
 template <bool HASH>
-int32_t dispatch_commit(zip_ctx *ctx, CommitArgs a, uint32_t *levels_done) {
-    const uint32_t cw = a.cw;
-    if (cw == 16384) {
-        a.nact = cw / 16;
-        *levels_done = 4;
-        return launch_commit<16, HASH, false>(ctx, a, 1024);
+int32_t dispatch_commit(zip_ctx *ctx, CommitArgs a, uint32_t grid, hipStream_t st) {
+    const CommitGeom g = commit_geom(a.cw, a.row_len);
+    a.nact = a.cw / g.e < g.threads ? a.cw / g.e : g.threads;
+    switch (g.e) {
+        case 16: return launch_commit<16, HASH, false>(ctx, a, g.threads, grid, st);
+        case 8: return launch_commit<8, HASH, true>(ctx, a, g.threads, grid, st);
+        case 4: return launch_commit<4, HASH, true>(ctx, a, g.threads, grid, st);
+        case 2: return launch_commit<2, HASH, true>(ctx, a, g.threads, grid, st);
+        default: return launch_commit<1, HASH, true>(ctx, a, g.threads, grid, st);
     }
-    if (cw >= 512) {
-        a.nact = cw / 8;
-        *levels_done = 3;
-        return launch_commit<8, HASH, true>(ctx, a, cw / 8);
-    }
-    if (cw == 256) {
-        a.nact = 64;
-        *levels_done = 2;
-        return launch_commit<4, HASH, true>(ctx, a, 64);
-    }
-    if (cw == 128) {
-        a.nact = 64;
-        *levels_done = 1;
-        return launch_commit<2, HASH, true>(ctx, a, 64);
-    }
-    a.nact = cw;  // cw <= 64: one entry per lane, upper lanes idle
-    *levels_done = 0;
-    return launch_commit<1, HASH, true>(ctx, a, 64);
 }
 
 template <int NL>
-int32_t launch_upper(zip_ctx *ctx, uint32_t *layers, uint32_t *roots, uint32_t trees, uint32_t cw,
+int32_t launch_upper(zip_ctx *ctx, hipStream_t st, uint32_t *layers, uint32_t *roots, uint32_t trees, uint32_t cw,
                      uint32_t level_in, uint32_t depth) {
     const uint64_t total = (uint64_t)trees * ((cw >> level_in) >> NL);
     const uint32_t threads = 256;
     const uint32_t blocks = (uint32_t)((total + threads - 1) / threads);
-    LaunchTimer t(ctx, "merkle_upper_kernel");
-    hipLaunchKernelGGL(merkle_upper_kernel<NL>, dim3(blocks), dim3(threads), 0, ctx->stream, layers, roots,
-                       trees, cw, level_in, depth);
+    LaunchTimer t(ctx, "merkle_upper_kernel", st);
+    hipLaunchKernelGGL(merkle_upper_kernel<NL>, dim3(blocks), dim3(threads), 0, st, layers, roots, trees, cw,
+                       level_in, depth);
     HIP_TRY(ctx, hipGetLastError());
     return ZIP_OK;
 }
 
-int32_t merkle_upper_levels(zip_ctx *ctx, uint32_t *layers, uint32_t *roots, uint32_t trees, uint32_t cw,
-                            uint32_t level, uint32_t depth) {
+int32_t merkle_upper_levels(zip_ctx *ctx, hipStream_t st, uint32_t *layers, uint32_t *roots, uint32_t trees,
+                            uint32_t cw, uint32_t level, uint32_t depth) {
     if (depth == 0) {
-        LaunchTimer t(ctx, "copy_roots_depth0_kernel");
-        hipLaunchKernelGGL(copy_roots_depth0_kernel, dim3((trees + 255) / 256), dim3(256), 0, ctx->stream,
-                           layers, roots, trees, cw);
+        LaunchTimer t(ctx, "copy_roots_depth0_kernel", st);
+        hipLaunchKernelGGL(copy_roots_depth0_kernel, dim3((trees + 255) / 256), dim3(256), 0, st, layers, roots,
+                           trees, cw);
         HIP_TRY(ctx, hipGetLastError());
         return ZIP_OK;
     }
@@ -348,16 +394,16 @@ int32_t merkle_upper_levels(zip_ctx *ctx, uint32_t *layers, uint32_t *roots, uin
         const uint32_t rem = depth - level;
         int32_t rc;
         if (rem >= 4) {
-            rc = launch_upper<4>(ctx, layers, roots, trees, cw, level, depth);
+            rc = launch_upper<4>(ctx, st, layers, roots, trees, cw, level, depth);
             level += 4;
         } else if (rem == 3) {
-            rc = launch_upper<3>(ctx, layers, roots, trees, cw, level, depth);
+            rc = launch_upper<3>(ctx, st, layers, roots, trees, cw, level, depth);
             level += 3;
         } else if (rem == 2) {
-            rc = launch_upper<2>(ctx, layers, roots, trees, cw, level, depth);
+            rc = launch_upper<2>(ctx, st, layers, roots, trees, cw, level, depth);
             level += 2;
         } else {
-            rc = launch_upper<1>(ctx, layers, roots, trees, cw, level, depth);
+            rc = launch_upper<1>(ctx, st, layers, roots, trees, cw, level, depth);
             level += 1;
         }
         if (rc) return rc;
@@ -389,8 +435,8 @@ struct CombineOut {
 
 // coeffs_d / q0_d: DEVICE pointers (already staged)
 template <int FL>
-int32_t run_combine_fl(zip_ctx *ctx, const int64_t *evals_d, const int64_t *coeffs_dv, const uint64_t *q0_dv,
-                       const HostField *hf, bool do_int, bool do_field, const CombineOut &out) {
+int32_t run_combine_fl(zip_ctx *ctx, hipStream_t st, const int64_t *evals_d, const int64_t *coeffs_dv,
+                       const uint64_t *q0_dv, const HostField *hf, bool do_int, bool do_field, const CombineOut &out) {
     const uint32_t R = ctx->rows_local, C = ctx->p.row_len;
     const uint32_t bx = (C + 255) / 256;
     uint32_t chunks = 512 / bx;
@@ -420,14 +466,14 @@ int32_t run_combine_fl(zip_ctx *ctx, const int64_t *evals_d, const int64_t *coef
         a.part_b = pb.as<uint64_t>();
     }
     {
-        LaunchTimer t(ctx, "combine_rows_kernel");
+        LaunchTimer t(ctx, "combine_rows_kernel", st);
         const dim3 grid(bx, chunks), block(256);
         if (do_int && do_field)
-            hipLaunchKernelGGL((combine_rows_kernel<FL, true, true>), grid, block, 0, ctx->stream, a);
+            hipLaunchKernelGGL((combine_rows_kernel<FL, true, true>), grid, block, 0, st, a);
         else if (do_int)
-            hipLaunchKernelGGL((combine_rows_kernel<FL, true, false>), grid, block, 0, ctx->stream, a);
+            hipLaunchKernelGGL((combine_rows_kernel<FL, true, false>), grid, block, 0, st, a);
         else
-            hipLaunchKernelGGL((combine_rows_kernel<FL, false, true>), grid, block, 0, ctx->stream, a);
+            hipLaunchKernelGGL((combine_rows_kernel<FL, false, true>), grid, block, 0, st, a);
         HIP_TRY(ctx, hipGetLastError());
     }
     FinalizeArgs fa{};
@@ -443,26 +489,28 @@ int32_t run_combine_fl(zip_ctx *ctx, const int64_t *evals_d, const int64_t *coef
     FieldDev<FL> fd{};
     if (hf) fd = to_dev<FL>(*hf);
     {
-        LaunchTimer t(ctx, "combine_finalize_kernel");
+        LaunchTimer t(ctx, "combine_finalize_kernel", st);
         const dim3 grid(bx), block(256);
         if (do_int && do_field)
-            hipLaunchKernelGGL((combine_finalize_kernel<FL, true, true>), grid, block, 0, ctx->stream, fa, fd);
+            hipLaunchKernelGGL((combine_finalize_kernel<FL, true, true>), grid, block, 0, st, fa, fd);
         else if (do_int)
-            hipLaunchKernelGGL((combine_finalize_kernel<FL, true, false>), grid, block, 0, ctx->stream, fa, fd);
+            hipLaunchKernelGGL((combine_finalize_kernel<FL, true, false>), grid, block, 0, st, fa, fd);
         else
-            hipLaunchKernelGGL((combine_finalize_kernel<FL, false, true>), grid, block, 0, ctx->stream, fa, fd);
+            hipLaunchKernelGGL((combine_finalize_kernel<FL, false, true>), grid, block, 0, st, fa, fd);
         HIP_TRY(ctx, hipGetLastError());
     }
     return ZIP_OK;
 }
 
 int32_t run_combine(zip_ctx *ctx, const int64_t *evals_d, const int64_t *coeffs_dv, const uint64_t *q0_dv,
-                    const HostField *hf, bool do_int, bool do_field, const CombineOut &out) {
+                    const HostField *hf, bool do_int, bool do_field, const CombineOut &out,
+                    hipStream_t st = nullptr) {
+    if (!st) st = ctx->stream;
     const uint32_t fl = hf ? hf->fl : 4;
     switch (fl) {
-        case 2: return run_combine_fl<2>(ctx, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out);
-        case 3: return run_combine_fl<3>(ctx, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out);
-        default: return run_combine_fl<4>(ctx, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out);
+        case 2: return run_combine_fl<2>(ctx, st, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out);
+        case 3: return run_combine_fl<3>(ctx, st, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out);
+        default: return run_combine_fl<4>(ctx, st, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out);
     }
 }
 
@@ -474,10 +522,11 @@ int32_t check_cols(zip_ctx *ctx, const uint32_t *cols_h, uint32_t n_cols) {
     return ZIP_OK;
 }
 
-// cols_dv: DEVICE pointer (already staged)
-int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d) {
+// cols_dv: DEVICE pointer (already staged).  Emits the openings of rows [row_lo, row_hi).
+int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d,
+                         uint32_t row_lo, uint32_t row_hi) {
     zip_ctx *ctx = c->ctx;
-    if (n_cols == 0) return ZIP_OK;
+    if (n_cols == 0 || row_hi <= row_lo) return ZIP_OK;
     OpenColsArgs a{};
     a.rows = c->rows;
     a.layers = reinterpret_cast<const uint64_t *>(c->layers);
@@ -487,11 +536,42 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
     a.cw = ctx->p.codeword_len;
     a.depth = ctx->depth;
     a.k_limbs = ctx->p.k_limbs;
-    a.rows_per_block = 64;
-    const dim3 grid(n_cols, (ctx->rows_local + a.rows_per_block - 1) / a.rows_per_block), block(256);
+    a.row_lo = row_lo;
+    a.row_hi = row_hi;
+    a.rows_per_block = (row_hi - row_lo) < 32 ? (row_hi - row_lo) : 32;  // the value copy needs <= 128
+    static const int knob_prio = getenv("ZIP_HIP_GATHER_PRIO") ? atoi(getenv("ZIP_HIP_GATHER_PRIO")) : 1;
+    a.prio = (uint32_t)knob_prio;
+    const size_t lds = (size_t)a.rows_per_block * (8 + 32 * (size_t)ctx->depth);
+    const dim3 grid(n_cols, (row_hi - row_lo + a.rows_per_block - 1) / a.rows_per_block), block(256);
     LaunchTimer t(ctx, "open_columns_kernel");
-    hipLaunchKernelGGL(open_columns_kernel, grid, block, 0, ctx->stream, a);
+    if (2 * ctx->depth + 1 <= 32)
+        hipLaunchKernelGGL(open_columns_kernel<32>, grid, block, lds, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(open_columns_kernel<64>, grid, block, lds, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
+    return ZIP_OK;
+}
+
+// All chunks, each gated on the arrival counter of the (possibly still running) persistent
+// commit kernel: the memory-bound gather of chunk k runs beside the hashing of later chunks.
+int32_t run_open_columns_pipelined(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d) {
+    zip_ctx *ctx = c->ctx;
+    if (!c->chunk_done) {
+        int32_t rc = wait_ready(c, ctx->stream);
+        if (rc) return rc;
+        return run_open_columns(c, cols_dv, n_cols, out_d, 0, ctx->rows_local);
+    }
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, c->zeroed, 0));
+    for (size_t k = 0; k + 1 < c->bounds.size(); k++) {
+        {
+            LaunchTimer t(ctx, "wait_counter_kernel");
+            hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, ctx->stream, c->chunk_done + k, c->expected[k],
+                               0u, ctx->timeout_flag_d, 200000000ull /* 2 s at 100 MHz */);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        int32_t rc = run_open_columns(c, cols_dv, n_cols, out_d, c->bounds[k], c->bounds[k + 1]);
+        if (rc) return rc;
+    }
     return ZIP_OK;
 }
 
@@ -500,10 +580,19 @@ size_t column_bytes(const zip_ctx *ctx) {
 }
 
 // copies a device result to the caller's buffer (host: synchronous)
+int32_t check_timeout(zip_ctx *ctx) {
+    if (ctx->timeout_flag_h && *ctx->timeout_flag_h) {
+        *ctx->timeout_flag_h = 0;
+        return fail(ctx, ZIP_ERR_HIP, "a pipeline stage waited 2 s for the commit kernel and gave up");
+    }
+    return ZIP_OK;
+}
+
 int32_t deliver(zip_ctx *ctx, void *dst, zip_mem_kind kind, const void *src_d, size_t bytes) {
     if (kind == ZIP_MEM_HOST) {
         HIP_TRY(ctx, hipMemcpyAsync(dst, src_d, bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return check_timeout(ctx);
     } else if (dst != src_d) {
         HIP_TRY(ctx, hipMemcpyAsync(dst, src_d, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     }
@@ -582,7 +671,42 @@ int32_t zip_ctx_create(const zip_params *p, zip_ctx **out) {
     int32_t rc = ZIP_OK;
     do {
         if (hipSetDevice(ctx->device) != hipSuccess) { rc = ZIP_ERR_NO_DEVICE; break; }
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
+        // the VALU-bound producers get dispatch priority; the memory-bound consumers on `stream`
+        // fill whatever wave slots / LDS the big commit workgroups leave free
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // numerically lower = higher priority
+        if (getenv("ZIP_HIP_NO_PRIORITY")) prio_hi = prio_lo;
+        if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+            hipStreamCreateWithPriority(&ctx->s_commit, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&ctx->s_upper, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&ctx->s_aux, hipStreamNonBlocking, prio_lo) != hipSuccess) {
+            rc = ZIP_ERR_HIP;
+            break;
+        }
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cus > 0)
+            ctx->num_cus = (uint32_t)cus;
+        // one pinned block: [0, 4096) pipeline status words, [4096, ...) staging of small inputs
+        ctx->stage_cap = (size_t)1 << 20;
+        if (hipHostMalloc((void **)&ctx->pinned_base, 4096 + ctx->stage_cap, hipHostMallocDefault) != hipSuccess) {
+            ctx->stage_cap = 0;
+            rc = ZIP_ERR_ALLOC;
+            break;
+        }
+        ctx->timeout_flag_h = reinterpret_cast<uint32_t *>(ctx->pinned_base);
+        ctx->stage_h = ctx->pinned_base + 4096;
+        if (hipHostGetDevicePointer((void **)&ctx->timeout_flag_d, ctx->timeout_flag_h, 0) != hipSuccess) {
+            rc = ZIP_ERR_ALLOC;
+            break;
+        }
+        *ctx->timeout_flag_h = 0;
+        // pipeline chunks: the persistent commit kernel publishes its rows in this many groups
+        ctx->n_chunks = rows_local >= 1024 ? 4 : 1;
+        if (const char *env = getenv("ZIP_HIP_CHUNKS")) {
+            const long v = strtol(env, nullptr, 10);
+            if (v >= 1 && v <= 64) ctx->n_chunks = (uint32_t)v;
+        }
+        if (ctx->n_chunks > rows_local) ctx->n_chunks = rows_local;
         const size_t pb = (size_t)p->codeword_len * 4;
         if (hipMalloc((void **)&ctx->perm1_d, pb) != hipSuccess || hipMalloc((void **)&ctx->perm2_d, pb) != hipSuccess) {
             rc = ZIP_ERR_ALLOC;
@@ -605,6 +729,9 @@ int32_t zip_ctx_create(const zip_params *p, zip_ctx **out) {
 void zip_ctx_destroy(zip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->s_commit) (void)hipStreamSynchronize(ctx->s_commit);
+    if (ctx->s_upper) (void)hipStreamSynchronize(ctx->s_upper);
+    if (ctx->s_aux) (void)hipStreamSynchronize(ctx->s_aux);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
     for (auto &kv : ctx->live_blocks) (void)hipFree(kv.first);
@@ -613,7 +740,12 @@ void zip_ctx_destroy(zip_ctx *ctx) {
         (void)hipEventDestroy(pe.stop);
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-    if (ctx->stage_h) (void)hipHostFree(ctx->stage_h);
+    for (auto e : ctx->dep_event_pool) (void)hipEventDestroy(e);
+    if (ctx->s_commit) (void)hipStreamDestroy(ctx->s_commit);
+    if (ctx->s_upper) (void)hipStreamDestroy(ctx->s_upper);
+    if (ctx->s_aux) (void)hipStreamDestroy(ctx->s_aux);
+    if (ctx->stage_big) (void)hipHostFree(ctx->stage_big);
+    if (ctx->pinned_base) (void)hipHostFree(ctx->pinned_base);
     if (ctx->perm1_d) (void)hipFree(ctx->perm1_d);
     if (ctx->perm2_d) (void)hipFree(ctx->perm2_d);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -624,8 +756,11 @@ const char *zip_ctx_last_error(const zip_ctx *ctx) { return ctx ? ctx->last_erro
 
 int32_t zip_ctx_synchronize(zip_ctx *ctx) {
     if (!ctx) return ZIP_ERR_NULL;
+    if (ctx->s_commit) HIP_TRY(ctx, hipStreamSynchronize(ctx->s_commit));
+    if (ctx->s_upper) HIP_TRY(ctx, hipStreamSynchronize(ctx->s_upper));
+    if (ctx->s_aux) HIP_TRY(ctx, hipStreamSynchronize(ctx->s_aux));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return ZIP_OK;
+    return check_timeout(ctx);
 }
 
 void *zip_ctx_stream(zip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
@@ -658,9 +793,25 @@ int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_k
         if (evals_kind == ZIP_MEM_HOST) {
             c->evals_bytes = n_evals * 8;
             if ((rc = pool_alloc(ctx, c->evals_bytes, (void **)&c->evals))) break;
-            hipError_t e = hipMemcpyAsync(c->evals, evals, c->evals_bytes, hipMemcpyHostToDevice, ctx->stream);
+            hipError_t e = hipMemcpyAsync(c->evals, evals, c->evals_bytes, hipMemcpyHostToDevice, ctx->s_commit);
             if (e != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "witness upload failed: %s", hipGetErrorString(e)); break; }
             evals_d = c->evals;
+        }
+        // ---- ONE persistent commit launch on s_commit; its chunks are consumed on s_upper ----
+        const CommitGeom geom = commit_geom(cw, C);
+        uint32_t G = ctx->num_cus * commit_wgs_per_cu(geom);
+        if (G > R) G = R;
+        const uint32_t rounds = (R + G - 1) / G;
+        // rows_per_chunk also batches the in-kernel upper tree levels, so keep it even without
+        // chunk signalling (commit_no_merkle has neither)
+        uint32_t nch = with_merkle ? ctx->n_chunks : 1;
+        if (nch > rounds) nch = rounds;
+        const uint32_t rpc = (rounds + nch - 1) / nch;
+        nch = (rounds + rpc - 1) / rpc;
+        c->bounds.resize(nch + 1);
+        for (uint32_t k = 0; k <= nch; k++) {
+            const uint64_t b = (uint64_t)k * rpc * G;
+            c->bounds[k] = b < R ? (uint32_t)b : R;
         }
         CommitArgs a{};
         a.evals = evals_d;
@@ -670,17 +821,32 @@ int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_k
         a.layers = c->layers;
         a.row_len = C;
         a.cw = cw;
-        uint32_t levels_done = 0;
-        rc = with_merkle ? dispatch_commit<true>(ctx, a, &levels_done) : dispatch_commit<false>(ctx, a, &levels_done);
+        a.num_rows = R;
+        a.rounds_per_chunk = rpc;
+        a.roots = c->roots;
+        hipError_t e = hipSuccess;
+        if (with_merkle && nch > 1) {
+            if ((rc = pool_alloc(ctx, (size_t)nch * 4, (void **)&c->chunk_done))) break;
+            e = hipMemsetAsync(c->chunk_done, 0, (size_t)nch * 4, ctx->s_commit);
+            c->zeroed = take_dep_event(ctx);
+            if (e == hipSuccess) e = hipEventRecord(c->zeroed, ctx->s_commit);
+            a.chunk_done = c->chunk_done;
+            c->expected.resize(nch);
+            for (uint32_t k = 0; k < nch; k++) c->expected[k] = (R - c->bounds[k]) < G ? (R - c->bounds[k]) : G;
+        }
+        if (e != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "commit setup failed: %s", hipGetErrorString(e)); break; }
+        rc = with_merkle ? dispatch_commit<true>(ctx, a, G, ctx->s_commit) : dispatch_commit<false>(ctx, a, G, ctx->s_commit);
         if (rc) break;
-        if (with_merkle) {
-            if ((rc = merkle_upper_levels(ctx, c->layers, c->roots, R, cw, levels_done, ctx->depth))) break;
-            if (roots_out) {
-                if ((rc = deliver(ctx, roots_out, ZIP_MEM_HOST, c->roots, c->roots_bytes))) break;
-            }
+        c->done = take_dep_event(ctx);
+        e = hipEventRecord(c->done, ctx->s_commit);
+        if (e != hipSuccess) rc = fail(ctx, ZIP_ERR_HIP, "commit pipeline failed: %s", hipGetErrorString(e));
+        if (rc) break;
+        if (with_merkle && roots_out) {
+            if ((rc = wait_ready(c, ctx->stream))) break;
+            if ((rc = deliver(ctx, roots_out, ZIP_MEM_HOST, c->roots, c->roots_bytes))) break;
         }
         if (evals_kind == ZIP_MEM_HOST) {
-            hipError_t e = hipStreamSynchronize(ctx->stream);  // the caller's buffer is free to go
+            hipError_t e = hipStreamSynchronize(ctx->s_commit);  // the caller's buffer is free to go
             if (e != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "commit failed: %s", hipGetErrorString(e)); break; }
         }
     } while (0);
@@ -694,6 +860,15 @@ int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_k
 
 void zip_commitment_free(zip_commitment *c) {
     if (!c) return;
+    // nothing may still be reading or writing the buffers when they return to the pool
+    if (c->done) {
+        (void)hipEventSynchronize(c->done);
+        c->ctx->dep_event_pool.push_back(c->done);
+    }
+    if (c->zeroed) c->ctx->dep_event_pool.push_back(c->zeroed);
+    for (hipEvent_t e : c->aux) c->ctx->dep_event_pool.push_back(e);
+    if (c->ctx->stream) (void)hipStreamSynchronize(c->ctx->stream);
+    pool_release(c->ctx, c->chunk_done);
     pool_release(c->ctx, c->rows);
     pool_release(c->ctx, c->layers);
     pool_release(c->ctx, c->roots);
@@ -703,6 +878,9 @@ void zip_commitment_free(zip_commitment *c) {
 
 int32_t zip_commitment_device_ptrs(zip_commitment *c, uint64_t **rows, uint8_t **layers, uint8_t **roots) {
     if (!c) return ZIP_ERR_NULL;
+    // work enqueued on the ctx stream (zip_ctx_stream) after this call sees complete data
+    int32_t rc_ = wait_ready(c, c->ctx->stream);
+    if (rc_) return rc_;
     if (rows) *rows = c->rows;
     if (layers) *layers = reinterpret_cast<uint8_t *>(c->layers);
     if (roots) *roots = reinterpret_cast<uint8_t *>(c->roots);
@@ -714,6 +892,10 @@ int32_t zip_commit_download(zip_commitment *c, uint64_t *rows_out, uint8_t *laye
     zip_ctx *ctx = c->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t R = ctx->rows_local, cw = ctx->p.codeword_len;
+    {
+        int32_t rc_ = wait_ready(c, ctx->stream);
+        if (rc_) return rc_;
+    }
     if (rows_out) HIP_TRY(ctx, hipMemcpyAsync(rows_out, c->rows, c->rows_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (layers_out) {
         if (!c->layers) return fail(ctx, ZIP_ERR_INVALID_PARAM, "commitment has no Merkle trees (commit_no_merkle)");
@@ -821,7 +1003,7 @@ int32_t zip_open_columns(zip_commitment *c, const uint32_t *cols, uint32_t n_col
     si.bytes[0] = (size_t)n_cols * 4;
     unsigned char *sb;
     if ((rc = stage_small(ctx, si, small, &sb))) return rc;
-    if ((rc = run_open_columns(c, reinterpret_cast<const uint32_t *>(sb), n_cols, out_d))) return rc;
+    if ((rc = run_open_columns_pipelined(c, reinterpret_cast<const uint32_t *>(sb), n_cols, out_d))) return rc;
     if (out_kind == ZIP_MEM_HOST) return deliver(ctx, wire_out, ZIP_MEM_HOST, out_d, bytes);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the pinned staging buffer is free again
     return ZIP_OK;
@@ -916,14 +1098,33 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
     si.bytes[2] = (size_t)n_cols * 4;
     unsigned char *sb;
     if ((rc = stage_small(ctx, si, small, &sb))) return rc;
-    if ((rc = run_combine(ctx, evals_d, reinterpret_cast<const int64_t *>(sb + si.off[0]),
-                          reinterpret_cast<const uint64_t *>(sb + si.off[1]), &hf, !single, true, o)))
+    // The two row combinations do not depend on the commitment: they run on their own stream
+    // beside the column openings (and beside a commit that is still in flight).
+    static const bool combine_last = getenv("ZIP_HIP_COMBINE_LAST") != nullptr;
+    hipEvent_t staged = take_dep_event(ctx), combined = take_dep_event(ctx);
+    c->aux.push_back(staged);
+    c->aux.push_back(combined);
+    if (!combine_last) {
+        HIP_TRY(ctx, hipEventRecord(staged, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, staged, 0));
+        if ((rc = run_combine(ctx, evals_d, reinterpret_cast<const int64_t *>(sb + si.off[0]),
+                              reinterpret_cast<const uint64_t *>(sb + si.off[1]), &hf, !single, true, o, ctx->s_aux)))
+            return rc;
+        HIP_TRY(ctx, hipEventRecord(combined, ctx->s_aux));
+    }
+    if ((rc = run_open_columns_pipelined(c, reinterpret_cast<const uint32_t *>(sb + si.off[2]), n_cols,
+                                         out_d + u_bytes)))
         return rc;
-    if ((rc = run_open_columns(c, reinterpret_cast<const uint32_t *>(sb + si.off[2]), n_cols, out_d + u_bytes)))
-        return rc;
+    if (combine_last) {
+        if ((rc = run_combine(ctx, evals_d, reinterpret_cast<const int64_t *>(sb + si.off[0]),
+                              reinterpret_cast<const uint64_t *>(sb + si.off[1]), &hf, !single, true, o)))
+            return rc;
+    } else {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, combined, 0));
+    }
     if (out_kind == ZIP_MEM_HOST) return deliver(ctx, proof_out, ZIP_MEM_HOST, out_d, total);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // small host inputs (coeffs, cols, q0) were consumed
-    return ZIP_OK;
+    return check_timeout(ctx);
 }
 
 int32_t zip_sum_partials(zip_ctx *ctx, const uint64_t *uparts, const uint64_t *fparts, uint32_t n_parts,
@@ -998,7 +1199,7 @@ int32_t zip_merkle_trees(int32_t device, const uint64_t *leaves, uint32_t leaf_l
             default: hipLaunchKernelGGL(merkle_leaves_kernel<8>, grid, block, 0, ctx->stream, L, Y, num_trees, n); break;
         }
         if (hipGetLastError() != hipSuccess) { rc = ZIP_ERR_HIP; break; }
-        if ((rc = merkle_upper_levels(ctx, Y, static_cast<uint32_t *>(roots_d), num_trees, n, 0, depth))) break;
+        if ((rc = merkle_upper_levels(ctx, ctx->stream, Y, static_cast<uint32_t *>(roots_d), num_trees, n, 0, depth))) break;
         hipError_t e = hipMemcpy2DAsync(layers_out, out_w, layers_d, (size_t)2 * n * 32, out_w, num_trees,
                                         kind == ZIP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
                                         ctx->stream);
