@@ -1,0 +1,83 @@
+/*
+ * zinc_zip_host.h -- C facade of libzinc_zip.so, the C++ mirror (zinc_amd/host/zinc_zip.hpp) of
+ * the HOST side of zinc::zip: what stays in the Rust crate in the real integration (Fiat-Shamir
+ * transcript, permutation-seed expansion, the eq tensor, parameter checks) driving the HIP
+ * library through include/zip_hip.h.  The facade exists so that tests and tools can exercise
+ * that layer through ctypes; it adds no behaviour of its own.
+ *
+ * Return codes: 0 ok; ZINC_ERR_INVALID_PARAM = zip::Error::InvalidPcsParam; ZINC_ERR_PANIC = a
+ * place where the reference panics (assert!/expect); ZINC_ERR_DEVICE = HIP library failure.
+ * zinc_last_error() returns the message of the calling thread's last failure.
+ */
+#ifndef ZINC_ZIP_HOST_H
+#define ZINC_ZIP_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZINC_OK 0
+#define ZINC_ERR_INVALID_PARAM (-1)
+#define ZINC_ERR_PANIC (-2)
+#define ZINC_ERR_DEVICE (-3)
+#define ZINC_ERR_NULL (-4)
+
+const char *zinc_last_error(void);
+
+/* KeccakTranscript (src/transcript.rs) */
+typedef struct zinc_transcript zinc_transcript;
+zinc_transcript *zinc_transcript_new(void);
+void zinc_transcript_free(zinc_transcript *t);
+void zinc_transcript_absorb(zinc_transcript *t, const uint8_t *bytes, size_t len);
+uint64_t zinc_transcript_get_u64(zinc_transcript *t);
+void zinc_transcript_get_integer_challenges(zinc_transcript *t, size_t n, int64_t *out);
+/* get_challenge::<RandomField<limbs>>: Montgomery limbs of the challenge */
+int32_t zinc_transcript_get_challenge(zinc_transcript *t, const uint64_t *modulus, uint32_t limbs, uint64_t *out);
+
+/* field helpers (src/field/config.rs, src/conversion.rs, src/sumcheck/utils.rs) */
+int32_t zinc_field_constants(const uint64_t *modulus, uint32_t limbs, uint64_t *r, uint64_t *r2, uint64_t *inv);
+int32_t zinc_field_mul(const uint64_t *modulus, uint32_t limbs, const uint64_t *a, const uint64_t *b, uint64_t *out);
+int32_t zinc_map_to_field_i64(const uint64_t *modulus, uint32_t limbs, const int64_t *v, size_t n, uint64_t *out);
+int32_t zinc_build_eq_x_r(const uint64_t *modulus, uint32_t limbs, const uint64_t *r, uint32_t nvars, uint64_t *out);
+
+/* shuffle_seeded on the identity (src/zip/utils.rs:139-142; rand 0.9 restated, parity unpinned) */
+void zinc_shuffle_seeded_perm(uint64_t seed, uint32_t len, uint32_t *perm);
+
+/* RaaCode::new (src/zip/code_raa.rs:35-86).  transcript == NULL uses MockTranscript (seeds 1, 2). */
+typedef struct {
+    uint32_t row_len, repetition_factor, num_column_opening, num_proximity_testing;
+    uint64_t perm_1_seed, perm_2_seed;
+} zinc_raa_code;
+int32_t zinc_raa_code_new(uint64_t poly_size, zinc_transcript *transcript, zinc_raa_code *out);
+
+/* MultilinearZip::setup / commit / open (src/zip/pcs/structs.rs:79-91, commit.rs:50-119, open_z.rs:22-40) */
+typedef struct zinc_zip_params zinc_zip_params;
+typedef struct zinc_zip_data zinc_zip_data;
+int32_t zinc_zip_setup(uint64_t poly_size, const zinc_raa_code *code, int32_t device, zinc_zip_params **out);
+void zinc_zip_params_free(zinc_zip_params *pp);
+void zinc_zip_params_geometry(const zinc_zip_params *pp, uint32_t *num_vars, uint32_t *num_rows, uint32_t *row_len,
+                              uint32_t *codeword_len);
+/* roots_out: num_rows * 32 bytes (ignored when with_merkle == 0) */
+int32_t zinc_zip_commit(const zinc_zip_params *pp, const int64_t *evals, size_t n_evals, uint32_t poly_num_vars,
+                        int32_t with_merkle, uint8_t *roots_out, zinc_zip_data **out);
+void zinc_zip_data_free(zinc_zip_data *d);
+
+/* PcsTranscript (src/zip/pcs_transcript.rs) */
+typedef struct zinc_pcs_transcript zinc_pcs_transcript;
+zinc_pcs_transcript *zinc_pcs_transcript_new(void);
+void zinc_pcs_transcript_free(zinc_pcs_transcript *t);
+size_t zinc_pcs_transcript_len(const zinc_pcs_transcript *t);
+void zinc_pcs_transcript_copy(const zinc_pcs_transcript *t, uint8_t *out); /* into_proof() */
+/* the Fiat-Shamir state after the calls so far, as one more u64 squeeze (for equality checks) */
+uint64_t zinc_pcs_transcript_probe(const zinc_pcs_transcript *t);
+
+/* point: point_len field elements, Montgomery limbs */
+int32_t zinc_zip_open(const zinc_zip_params *pp, const int64_t *evals, size_t n_evals, uint32_t poly_num_vars,
+                      const zinc_zip_data *data, const uint64_t *point, size_t point_len, const uint64_t *modulus,
+                      uint32_t limbs, zinc_pcs_transcript *transcript);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

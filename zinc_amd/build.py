@@ -61,8 +61,9 @@ def build_host(force=False, verbose=False):
     target = os.path.join(LIB, "libzinc_zip.so")
     deps = srcs + _sources(HOST, (".hpp", ".h")) + _sources(INCLUDE, (".h",))
     if force or _newer(target, deps):
+        build_hip(force=False, verbose=verbose)  # libzinc_zip.so links against the HIP library
         cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wextra", f"-I{INCLUDE}", f"-I{HOST}",
-               "-o", target, *srcs, "-ldl"]
+               "-o", target, *srcs, f"-L{LIB}", "-lzip_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -1,0 +1,182 @@
+// C facade over zinc_zip.hpp (include/zinc_zip_host.h): opaque handles + error-code mapping.
+#include <string>
+
+#include "zinc_zip.hpp"
+#include "zinc_zip_host.h"
+
+using namespace zinc;
+using namespace zinc::zip;
+
+struct zinc_transcript { KeccakTranscript t; };
+struct zinc_zip_params { MultilinearZipParams pp; };
+struct zinc_zip_data { MultilinearZipData d; };
+struct zinc_pcs_transcript { PcsTranscript t; };
+
+namespace {
+thread_local std::string g_err;
+
+template <class F>
+int32_t guarded(F &&f) {
+    try {
+        f();
+        return ZINC_OK;
+    } catch (const ZipError &e) {
+        g_err = e.what();
+        return e.kind == ZipError::InvalidPcsParam ? ZINC_ERR_INVALID_PARAM : ZINC_ERR_DEVICE;
+    } catch (const std::logic_error &e) {  // where the reference panics
+        g_err = e.what();
+        return ZINC_ERR_PANIC;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return ZINC_ERR_DEVICE;
+    }
+}
+Limbs load(const uint64_t *p, uint32_t n) {
+    Limbs l{};
+    for (uint32_t i = 0; i < n; i++) l[i] = p[i];
+    return l;
+}
+}  // namespace
+
+extern "C" {
+
+const char *zinc_last_error(void) { return g_err.c_str(); }
+
+zinc_transcript *zinc_transcript_new(void) { return new zinc_transcript(); }
+void zinc_transcript_free(zinc_transcript *t) { delete t; }
+void zinc_transcript_absorb(zinc_transcript *t, const uint8_t *bytes, size_t len) { t->t.absorb(bytes, len); }
+uint64_t zinc_transcript_get_u64(zinc_transcript *t) { return t->t.get_u64(); }
+void zinc_transcript_get_integer_challenges(zinc_transcript *t, size_t n, int64_t *out) {
+    const auto v = t->t.get_integer_challenges_i64(n);
+    for (size_t i = 0; i < n; i++) out[i] = v[i];
+}
+int32_t zinc_transcript_get_challenge(zinc_transcript *t, const uint64_t *modulus, uint32_t limbs, uint64_t *out) {
+    return guarded([&] {
+        const FieldConfig f = FieldConfig::make(modulus, limbs);
+        const Limbs c = t->t.get_challenge(f);
+        for (uint32_t i = 0; i < limbs; i++) out[i] = c[i];
+    });
+}
+
+int32_t zinc_field_constants(const uint64_t *modulus, uint32_t limbs, uint64_t *r, uint64_t *r2, uint64_t *inv) {
+    return guarded([&] {
+        const FieldConfig f = FieldConfig::make(modulus, limbs);
+        for (uint32_t i = 0; i < limbs; i++) {
+            r[i] = f.r[i];
+            r2[i] = f.r2[i];
+        }
+        *inv = f.inv;
+    });
+}
+int32_t zinc_field_mul(const uint64_t *modulus, uint32_t limbs, const uint64_t *a, const uint64_t *b, uint64_t *out) {
+    return guarded([&] {
+        const FieldConfig f = FieldConfig::make(modulus, limbs);
+        Limbs x = load(a, limbs);
+        f.mul_assign(x, load(b, limbs));
+        for (uint32_t i = 0; i < limbs; i++) out[i] = x[i];
+    });
+}
+int32_t zinc_map_to_field_i64(const uint64_t *modulus, uint32_t limbs, const int64_t *v, size_t n, uint64_t *out) {
+    return guarded([&] {
+        const FieldConfig f = FieldConfig::make(modulus, limbs);
+        for (size_t k = 0; k < n; k++) {
+            const Limbs x = map_to_field(f, v[k]);
+            for (uint32_t i = 0; i < limbs; i++) out[k * limbs + i] = x[i];
+        }
+    });
+}
+int32_t zinc_build_eq_x_r(const uint64_t *modulus, uint32_t limbs, const uint64_t *r, uint32_t nvars, uint64_t *out) {
+    return guarded([&] {
+        const FieldConfig f = FieldConfig::make(modulus, limbs);
+        std::vector<Limbs> rv(nvars);
+        for (uint32_t t = 0; t < nvars; t++) rv[t] = load(r + (size_t)t * limbs, limbs);
+        const auto eq = build_eq_x_r(f, rv.data(), nvars);
+        for (size_t k = 0; k < eq.size(); k++)
+            for (uint32_t i = 0; i < limbs; i++) out[k * limbs + i] = eq[k][i];
+    });
+}
+
+void zinc_shuffle_seeded_perm(uint64_t seed, uint32_t len, uint32_t *perm) {
+    const auto p = shuffle_seeded_perm(seed, len);
+    for (uint32_t i = 0; i < len; i++) perm[i] = p[i];
+}
+
+int32_t zinc_raa_code_new(uint64_t poly_size, zinc_transcript *transcript, zinc_raa_code *out) {
+    if (!out) return ZINC_ERR_NULL;
+    return guarded([&] {
+        RaaCode c;
+        if (transcript) {
+            KeccakSeedSource src(transcript->t);
+            c = RaaCode::make(LinearCodeSpec{}, poly_size, src);
+        } else {
+            MockTranscript mock;
+            c = RaaCode::make(LinearCodeSpec{}, poly_size, mock);
+        }
+        *out = {c.row_len, c.repetition_factor, c.num_column_opening, c.num_proximity_testing, c.perm_1_seed, c.perm_2_seed};
+    });
+}
+
+int32_t zinc_zip_setup(uint64_t poly_size, const zinc_raa_code *code, int32_t device, zinc_zip_params **out) {
+    if (!code || !out) return ZINC_ERR_NULL;
+    *out = nullptr;
+    return guarded([&] {
+        RaaCode c;
+        c.row_len = code->row_len;
+        c.repetition_factor = code->repetition_factor;
+        c.num_column_opening = code->num_column_opening;
+        c.num_proximity_testing = code->num_proximity_testing;
+        c.perm_1_seed = code->perm_1_seed;
+        c.perm_2_seed = code->perm_2_seed;
+        auto *pp = new zinc_zip_params{MultilinearZip::setup(poly_size, c, device)};
+        *out = pp;
+    });
+}
+void zinc_zip_params_free(zinc_zip_params *pp) { delete pp; }
+void zinc_zip_params_geometry(const zinc_zip_params *pp, uint32_t *num_vars, uint32_t *num_rows, uint32_t *row_len,
+                              uint32_t *codeword_len) {
+    *num_vars = pp->pp.num_vars;
+    *num_rows = pp->pp.num_rows;
+    *row_len = pp->pp.linear_code.row_len;
+    *codeword_len = pp->pp.linear_code.codeword_len();
+}
+
+int32_t zinc_zip_commit(const zinc_zip_params *pp, const int64_t *evals, size_t n_evals, uint32_t poly_num_vars,
+                        int32_t with_merkle, uint8_t *roots_out, zinc_zip_data **out) {
+    if (!pp || !out) return ZINC_ERR_NULL;
+    *out = nullptr;
+    return guarded([&] {
+        if (with_merkle) {
+            auto res = MultilinearZip::commit(pp->pp, evals, n_evals, poly_num_vars);
+            if (roots_out) std::memcpy(roots_out, res.second.roots.data(), res.second.roots.size() * 32);
+            *out = new zinc_zip_data{std::move(res.first)};
+        } else {
+            *out = new zinc_zip_data{MultilinearZip::commit_no_merkle(pp->pp, evals, n_evals, poly_num_vars)};
+        }
+    });
+}
+void zinc_zip_data_free(zinc_zip_data *d) { delete d; }
+
+zinc_pcs_transcript *zinc_pcs_transcript_new(void) { return new zinc_pcs_transcript(); }
+void zinc_pcs_transcript_free(zinc_pcs_transcript *t) { delete t; }
+size_t zinc_pcs_transcript_len(const zinc_pcs_transcript *t) { return t->t.stream.size(); }
+void zinc_pcs_transcript_copy(const zinc_pcs_transcript *t, uint8_t *out) {
+    std::memcpy(out, t->t.stream.data(), t->t.stream.size());
+}
+uint64_t zinc_pcs_transcript_probe(const zinc_pcs_transcript *t) {
+    KeccakTranscript copy = t->t.fs_transcript;
+    return copy.get_u64();
+}
+
+int32_t zinc_zip_open(const zinc_zip_params *pp, const int64_t *evals, size_t n_evals, uint32_t poly_num_vars,
+                      const zinc_zip_data *data, const uint64_t *point, size_t point_len, const uint64_t *modulus,
+                      uint32_t limbs, zinc_pcs_transcript *transcript) {
+    if (!pp || !data || !transcript) return ZINC_ERR_NULL;
+    return guarded([&] {
+        const FieldConfig f = FieldConfig::make(modulus, limbs);
+        std::vector<Limbs> pt(point_len);
+        for (size_t i = 0; i < point_len; i++) pt[i] = load(point + i * limbs, limbs);
+        MultilinearZip::open(pp->pp, evals, n_evals, poly_num_vars, data->d, pt.data(), point_len, f, transcript->t);
+    });
+}
+
+}  // extern "C"

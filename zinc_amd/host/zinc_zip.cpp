@@ -1,0 +1,626 @@
+// Host side of the Zip commit/open path (see zinc_zip.hpp).  Only sequential, tiny work lives
+// here; MultilinearZip::commit / open forward every O(n) loop to libzip_hip.so.
+#include "zinc_zip.hpp"
+
+#include <algorithm>
+
+namespace zinc {
+
+using u128 = unsigned __int128;
+
+// ============================================================================ Keccak-256
+// sha3 crate `Keccak256` (src/transcript.rs:2): Keccak-f[1600], rate 136, domain byte 0x01.
+void Keccak256::permute(uint64_t a[25]) {
+    static const uint64_t RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    // rho rotation of lane (x, y), indexed x + 5y
+    static const int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    auto rol = [](uint64_t v, int n) { return n ? (v << n) | (v >> (64 - n)) : v; };
+    for (int round = 0; round < 24; round++) {
+        uint64_t c[5], d[5], b[25];
+        for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+        for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rol(c[(x + 1) % 5], 1);
+        for (int i = 0; i < 25; i++) a[i] ^= d[i % 5];
+        for (int x = 0; x < 5; x++)
+            for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rol(a[x + 5 * y], RHO[x + 5 * y]);  // rho + pi
+        for (int y = 0; y < 5; y++)
+            for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        a[0] ^= RC[round];
+    }
+}
+
+void Keccak256::absorb_block(const uint8_t *blk) {
+    for (int i = 0; i < 17; i++) {
+        uint64_t w;
+        std::memcpy(&w, blk + 8 * i, 8);  // little-endian host
+        st_[i] ^= w;
+    }
+    permute(st_);
+}
+
+void Keccak256::update(const uint8_t *data, size_t len) {
+    while (len) {
+        const size_t take = std::min<size_t>(136 - buflen_, len);
+        std::memcpy(buf_ + buflen_, data, take);
+        buflen_ += (uint32_t)take;
+        data += take;
+        len -= take;
+        if (buflen_ == 136) {
+            absorb_block(buf_);
+            buflen_ = 0;
+        }
+    }
+}
+
+std::array<uint8_t, 32> Keccak256::finalize() const {
+    Keccak256 c = *this;
+    std::memset(c.buf_ + c.buflen_, 0, 136 - c.buflen_);
+    c.buf_[c.buflen_] ^= 0x01;
+    c.buf_[135] ^= 0x80;
+    c.absorb_block(c.buf_);
+    std::array<uint8_t, 32> out;
+    std::memcpy(out.data(), c.st_, 32);
+    return out;
+}
+
+// ============================================================================ multi-limb helpers
+namespace {
+
+int cmp(const Limbs &a, const Limbs &b, uint32_t n) {
+    for (uint32_t i = n; i-- > 0;)
+        if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+    return 0;
+}
+bool add_in_place(Limbs &a, const Limbs &b, uint32_t n) {
+    u128 c = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        c += (u128)a[i] + b[i];
+        a[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    return c != 0;
+}
+void sub_in_place(Limbs &a, const Limbs &b, uint32_t n) {
+    uint64_t borrow = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const u128 d = (u128)a[i] - b[i] - borrow;
+        a[i] = (uint64_t)d;
+        borrow = (uint64_t)(d >> 64) & 1;
+    }
+}
+bool is_zero(const Limbs &a, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++)
+        if (a[i]) return false;
+    return true;
+}
+void negate(Limbs &a, uint32_t n) {  // two's complement
+    uint64_t carry = 1;
+    for (uint32_t i = 0; i < n; i++) {
+        a[i] = ~a[i] + carry;
+        carry = (carry && a[i] == 0) ? 1 : 0;
+    }
+}
+uint32_t bit_length(const Limbs &a, uint32_t n) {
+    for (uint32_t i = n; i-- > 0;)
+        if (a[i]) return 64 * i + 64 - (uint32_t)__builtin_clzll(a[i]);
+    return 0;
+}
+// a mod m for n-limb unsigned values (schoolbook shift-subtract; only used off the hot path)
+Limbs umod(const Limbs &a, const Limbs &m, uint32_t n) {
+    if (cmp(a, m, n) < 0) return a;
+    Limbs r{};
+    for (uint32_t b = bit_length(a, n); b-- > 0;) {
+        const bool top = r[n - 1] >> 63;
+        for (uint32_t i = n; i-- > 1;) r[i] = (r[i] << 1) | (r[i - 1] >> 63);
+        r[0] = (r[0] << 1) | ((a[b / 64] >> (b % 64)) & 1);
+        if (top || cmp(r, m, n) >= 0) sub_in_place(r, m, n);
+    }
+    return r;
+}
+
+// Tail shared by every FieldMap impl: the value and the MODULUS are read as signed Int<W>
+// (F::I = Int<N>, src/field.rs:280), `%=` is crypto-bigint's Int::rem (|lhs| mod |rhs|, sign of
+// lhs) and BigInt::from(Int) takes the magnitude (biginteger.rs:805-816); then times R^2.
+Limbs from_signed_words(const FieldConfig &f, Limbs words) {
+    const uint32_t n = f.limbs;
+    if (words[n - 1] >> 63) negate(words, n);
+    Limbs mod = f.modulus;
+    if (mod[n - 1] >> 63) negate(mod, n);
+    Limbs v = umod(words, mod, n);
+    f.mul_assign(v, f.r2);
+    return v;
+}
+
+}  // namespace
+
+// ============================================================================ FieldConfig
+FieldConfig FieldConfig::make(const uint64_t *modulus, uint32_t limbs) {
+    if (limbs == 0 || limbs > kMaxLimbs || !(modulus[0] & 1)) throw std::logic_error("FieldConfig: bad modulus");
+    FieldConfig f;
+    f.limbs = limbs;
+    for (uint32_t i = 0; i < limbs; i++) f.modulus[i] = modulus[i];
+    f.modulus_has_spare_bit = (modulus[limbs - 1] >> 63) == 0;
+    uint64_t inv = 1;  // config.rs:196-214
+    for (int i = 0; i < 63; i++) {
+        inv *= inv;
+        inv *= modulus[0];
+    }
+    f.inv = 0 - inv;
+    Limbs x{};
+    x[0] = 1;
+    auto dbl = [&](Limbs &v) {
+        const bool top = v[limbs - 1] >> 63;
+        for (uint32_t i = limbs; i-- > 1;) v[i] = (v[i] << 1) | (v[i - 1] >> 63);
+        v[0] <<= 1;
+        if (top || cmp(v, f.modulus, limbs) >= 0) sub_in_place(v, f.modulus, limbs);
+    };
+    for (uint32_t i = 0; i < 64 * limbs; i++) dbl(x);
+    f.r = x;
+    for (uint32_t i = 0; i < 64 * limbs; i++) dbl(x);
+    f.r2 = x;
+    return f;
+}
+
+void FieldConfig::reduce_modulus(Limbs &a, bool carry) const {
+    if (modulus_has_spare_bit) {
+        if (cmp(a, modulus, limbs) >= 0) sub_in_place(a, modulus, limbs);
+    } else if (carry || cmp(a, modulus, limbs) >= 0) {
+        sub_in_place(a, modulus, limbs);
+    }
+}
+
+// mul_naive (biginteger.rs:448-464) then montgomery_reduction (:532-560)
+void FieldConfig::mul_assign(Limbs &a, const Limbs &b) const {
+    const uint32_t N = limbs;
+    uint64_t t[2 * kMaxLimbs] = {0};
+    for (uint32_t i = 0; i < N; i++) {
+        uint64_t carry = 0;
+        for (uint32_t j = 0; j < N; j++) {
+            const u128 x = (u128)a[i] * b[j] + t[i + j] + carry;
+            t[i + j] = (uint64_t)x;
+            carry = (uint64_t)(x >> 64);
+        }
+        t[i + N] = carry;
+    }
+    uint64_t carry2 = 0;
+    for (uint32_t i = 0; i < N; i++) {
+        const uint64_t k = t[i] * inv;
+        uint64_t carry = 0;
+        for (uint32_t j = 0; j < N; j++) {
+            const u128 x = (u128)k * modulus[j] + t[i + j] + carry;
+            t[i + j] = (uint64_t)x;
+            carry = (uint64_t)(x >> 64);
+        }
+        const u128 y = (u128)t[i + N] + carry + carry2;
+        t[i + N] = (uint64_t)y;
+        carry2 = (uint64_t)(y >> 64);
+    }
+    for (uint32_t i = 0; i < N; i++) a[i] = t[N + i];
+    reduce_modulus(a, carry2 != 0);
+}
+
+void FieldConfig::add_assign(Limbs &a, const Limbs &b) const { reduce_modulus(a, add_in_place(a, b, limbs)); }
+
+void FieldConfig::sub_assign(Limbs &a, const Limbs &b) const {
+    if (cmp(b, a, limbs) > 0) add_in_place(a, modulus, limbs);
+    sub_in_place(a, b, limbs);
+}
+
+void FieldConfig::neg(Limbs &a) const {
+    if (is_zero(a, limbs)) return;
+    Limbs t = modulus;
+    sub_in_place(t, a, limbs);
+    a = t;
+}
+
+uint32_t FieldConfig::num_bits() const { return bit_length(modulus, limbs); }
+
+zip_field FieldConfig::to_abi() const {
+    zip_field z{};
+    z.limbs = limbs;
+    for (uint32_t i = 0; i < kMaxLimbs; i++) z.modulus[i] = i < limbs ? modulus[i] : 0;
+    return z;
+}
+
+Limbs map_to_field(const FieldConfig &f, int64_t v) {
+    Limbs w{};
+    w[0] = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;  // Integer::abs
+    Limbs r = from_signed_words(f, w);
+    if (v < 0) f.neg(r);
+    return r;
+}
+
+Limbs map_to_field_u128(const FieldConfig &f, uint64_t lo, uint64_t hi) {
+    Limbs w{};
+    w[0] = lo;
+    if (f.limbs > 1) w[1] = hi;
+    return from_signed_words(f, w);
+}
+
+std::vector<Limbs> build_eq_x_r(const FieldConfig &f, const Limbs *r, uint32_t nvars) {
+    if (nvars == 0) throw std::logic_error("r length is 0");  // ArithErrors::InvalidParameters
+    std::vector<Limbs> buf(2);
+    buf[0] = f.r;  // F::one()
+    f.sub_assign(buf[0], r[nvars - 1]);
+    buf[1] = r[nvars - 1];
+    for (uint32_t t = nvars - 1; t-- > 0;) {
+        std::vector<Limbs> res(buf.size() * 2);
+        for (size_t i = 0; i < res.size(); i++) {
+            Limbs tmp = r[t];
+            f.mul_assign(tmp, buf[i >> 1]);
+            if (i & 1) {
+                res[i] = tmp;
+            } else {
+                res[i] = buf[i >> 1];
+                f.sub_assign(res[i], tmp);
+            }
+        }
+        buf.swap(res);
+    }
+    return buf;
+}
+
+// ============================================================================ KeccakTranscript
+std::vector<uint8_t> KeccakTranscript::get_random_bytes(size_t length) {
+    std::vector<uint8_t> out;
+    out.reserve(length + 32);
+    for (int32_t counter = 0; out.size() < length; counter++) {
+        Keccak256 tmp = hasher_;
+        tmp.update({(uint8_t)(counter >> 24), (uint8_t)(counter >> 16), (uint8_t)(counter >> 8), (uint8_t)counter});
+        const auto h = tmp.finalize();
+        out.insert(out.end(), h.begin(), h.end());
+    }
+    out.resize(length);
+    return out;
+}
+
+void KeccakTranscript::get_integer_challenge(uint32_t n_limbs, uint64_t *out) {
+    for (uint32_t i = 0; i < n_limbs; i++) {
+        const auto ch = get_random_bytes(8);
+        hasher_.update({0x12});
+        hasher_.update(ch.data(), 8);
+        hasher_.update({0x34});
+        uint64_t w;
+        std::memcpy(&w, ch.data(), 8);  // u64::from_le_bytes
+        out[i] = w;
+    }
+}
+
+std::vector<int64_t> KeccakTranscript::get_integer_challenges_i64(size_t n) {
+    std::vector<int64_t> v(n);
+    for (size_t i = 0; i < n; i++) {
+        uint64_t w;
+        get_integer_challenge(1, &w);
+        v[i] = (int64_t)w;
+    }
+    return v;
+}
+
+static void to_be_bytes(const Limbs &v, uint32_t n, uint8_t *out) {
+    for (uint32_t i = 0; i < n; i++)
+        for (int b = 0; b < 8; b++) out[8 * (n - 1 - i) + (7 - b)] = (uint8_t)(v[i] >> (8 * b));
+}
+
+void KeccakTranscript::absorb_random_field(const FieldConfig &f, const Limbs &v) {
+    uint8_t buf[8 * kMaxLimbs];
+    hasher_.update({0x3});
+    to_be_bytes(f.modulus, f.limbs, buf);
+    hasher_.update(buf, 8 * f.limbs);
+    hasher_.update({0x5});
+    hasher_.update({0x1});
+    to_be_bytes(v, f.limbs, buf);
+    hasher_.update(buf, 8 * f.limbs);
+    hasher_.update({0x3});
+}
+
+Limbs KeccakTranscript::get_challenge(const FieldConfig &f) {
+    const auto ch = hasher_.finalize();  // get_challenge_limbs, transcript.rs:72-86
+    auto be64 = [&](int off) {
+        uint64_t w = 0;
+        for (int b = 0; b < 8; b++) w = (w << 8) | ch[off + b];
+        return w;
+    };
+    uint64_t lo0 = be64(8), lo1 = be64(0), hi0 = be64(24), hi1 = be64(16);
+    hasher_.update({0x00});
+    hasher_.update(ch.data(), 32);
+    hasher_.update({0x01});
+
+    const uint32_t cbits = f.num_bits() - 1;
+    auto mask128 = [](uint64_t &w0, uint64_t &w1, uint32_t keep) {
+        if (keep < 64) {
+            w0 &= (1ULL << keep) - 1;
+            w1 = 0;
+        } else if (keep == 64) {
+            w1 = 0;
+        } else if (keep < 128) {
+            w1 &= (1ULL << (keep - 64)) - 1;
+        }
+    };
+    if (f.limbs == 1) return map_to_field_u128(f, lo0 & ((1ULL << cbits) - 1), 0);
+    if (cbits < 128) {
+        mask128(lo0, lo1, cbits);
+        return map_to_field_u128(f, lo0, lo1);
+    }
+    if (cbits < 256) mask128(hi0, hi1, cbits - 128);
+    Limbs w{};
+    if (f.limbs > 2) w[2] = 1;  // BigInt::from_bits_le(bit 128)
+    Limbs two128 = from_signed_words(f, w);
+    Limbs a = map_to_field_u128(f, lo0, lo1);
+    const Limbs b = map_to_field_u128(f, hi0, hi1);
+    f.mul_assign(two128, b);
+    f.add_assign(a, two128);
+    return a;
+}
+
+namespace zip {
+
+// ============================================================================ shuffle_seeded
+// rand 0.9.2: StdRng = ChaCha12, seed_from_u64 = PCG32 expansion, SliceRandom::shuffle =
+// IncreasingUniform Fisher-Yates with Canon's-method random_range.  PARITY UNPINNED (see perm.py).
+namespace {
+struct ChaCha12 {
+    uint32_t key[8];
+    uint64_t counter = 0;
+    uint32_t buf[16];
+    int idx = 16;
+    explicit ChaCha12(uint64_t state) {
+        for (int i = 0; i < 8; i++) {
+            state = state * 6364136223846793005ULL + 11634580027462260723ULL;
+            const uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27), rot = (uint32_t)(state >> 59);
+            key[i] = (xs >> rot) | (xs << ((32 - rot) & 31));
+        }
+    }
+    static inline uint32_t rotl(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
+    void refill() {
+        uint32_t s[16] = {0x61707865, 0x3320646e, 0x79622d32, 0x6b206574}, x[16];
+        for (int i = 0; i < 8; i++) s[4 + i] = key[i];
+        s[12] = (uint32_t)counter;
+        s[13] = (uint32_t)(counter >> 32);
+        s[14] = s[15] = 0;
+        std::memcpy(x, s, sizeof x);
+        auto qr = [&](int a, int b, int c, int d) {
+            x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);
+            x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
+            x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);
+            x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+        };
+        for (int r = 0; r < 6; r++) {
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+        }
+        for (int i = 0; i < 16; i++) buf[i] = x[i] + s[i];
+        counter++;
+        idx = 0;
+    }
+    uint32_t next_u32() {
+        if (idx >= 16) refill();
+        return buf[idx++];
+    }
+    uint32_t random_range(uint32_t bound) {
+        const uint64_t m = (uint64_t)next_u32() * bound;
+        uint32_t result = (uint32_t)(m >> 32);
+        const uint32_t lo = (uint32_t)m;
+        if (lo > (uint32_t)(0u - bound)) {
+            const uint32_t hi2 = (uint32_t)(((uint64_t)next_u32() * bound) >> 32);
+            result += (uint32_t)(lo + hi2 < lo);
+        }
+        return result;
+    }
+};
+}  // namespace
+
+std::vector<uint32_t> shuffle_seeded_perm(uint64_t seed, uint32_t len) {
+    std::vector<uint32_t> perm(len);
+    for (uint32_t i = 0; i < len; i++) perm[i] = i;
+    if (len <= 1) return perm;
+    ChaCha12 rng(seed);
+    uint32_t n = 0, chunk = 0;
+    uint8_t remaining = 1;  // IncreasingUniform::new(rng, 0)
+    for (uint32_t i = 0; i < len; i++) {
+        const uint32_t next_n = n + 1;
+        uint8_t next_rem;
+        if (remaining > 0) {
+            next_rem = remaining - 1;
+        } else {
+            uint32_t product = next_n, current = next_n + 1;
+            while (((uint64_t)product * current) >> 32 == 0) product *= current++;
+            chunk = rng.random_range(product);
+            next_rem = (uint8_t)(current - next_n - 1);
+        }
+        uint32_t j;
+        if (next_rem == 0) {
+            j = chunk;
+        } else {
+            j = chunk % next_n;
+            chunk /= next_n;
+        }
+        remaining = next_rem;
+        n = next_n;
+        std::swap(perm[i], perm[j]);
+    }
+    return perm;
+}
+
+// ============================================================================ RaaCode
+static uint64_t isqrt(uint64_t x) {
+    uint64_t r = 0;
+    for (int b = 31; b >= 0; b--) {
+        const uint64_t t = r | (1ULL << b);
+        if (t * t <= x) r = t;
+    }
+    return r;
+}
+static uint64_t next_pow2(uint64_t x) {
+    uint64_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+static uint32_t ilog2(uint64_t x) { return 63u - (uint32_t)__builtin_clzll(x); }
+
+RaaCode RaaCode::make(const LinearCodeSpec &spec, uint64_t poly_size, SeedSource &transcript) {
+    RaaCode c;
+    const uint32_t num_vars = ilog2(poly_size);
+    c.row_len = (uint32_t)next_pow2(isqrt(1ULL << num_vars));  // code_raa.rs:43
+    c.repetition_factor = spec.repetition_factor;
+    c.num_column_opening = spec.num_column_opening;
+    c.num_proximity_testing = spec.num_proximity_testing;
+    // width assertion, code_raa.rs:53-72 (N = Int<1>: 64 bits, K = Int<4>: 256 bits)
+    const uint32_t rep_log = ilog2(next_pow2(spec.repetition_factor));
+    const uint32_t nv_even = (num_vars & 1) ? num_vars + 1 : num_vars;
+    const uint32_t width = 64 + nv_even + 2 * rep_log;
+    if (256 < width)
+        throw std::logic_error("Cannot fit " + std::to_string(width) + "-bit wide codeword entries in 256 bits integers");
+    c.perm_1_seed = transcript.get_u64();
+    c.perm_2_seed = transcript.get_u64();
+    return c;
+}
+
+// ============================================================================ PcsTranscript
+void PcsTranscript::write_field_elements(const FieldConfig &f, const Limbs *elems, size_t n) {
+    uint8_t be[8 * kMaxLimbs];
+    for (size_t i = 0; i < n; i++) {
+        fs_transcript.absorb_random_field(f, elems[i]);  // common_field_element
+        to_be_bytes(elems[i], f.limbs, be);
+        append(be, 8 * f.limbs);
+    }
+}
+
+size_t PcsTranscript::squeeze_challenge_idx(const FieldConfig &f, size_t cap) {
+    const Limbs ch = fs_transcript.get_challenge(f);
+    return (size_t)(uint32_t)ch[0] % cap;  // first 4 little-endian bytes of the Montgomery value
+}
+
+// ============================================================================ MultilinearZip
+static void check(zip_ctx *ctx, int32_t rc, const char *what) {
+    if (rc == ZIP_OK) return;
+    const std::string detail = ctx ? zip_ctx_last_error(ctx) : "";
+    const std::string msg = std::string(what) + ": " + zip_strerror(rc) + (detail.empty() ? "" : " (" + detail + ")");
+    if (rc == ZIP_ERR_SHAPE) throw std::logic_error(msg);  // the reference panics (assert_eq!)
+    if (rc == ZIP_ERR_INVALID_PARAM) throw ZipError(ZipError::InvalidPcsParam, msg);
+    throw ZipError(ZipError::Device, msg);
+}
+
+MultilinearZipParams MultilinearZip::setup(uint64_t poly_size, const RaaCode &code, int device) {
+    if (poly_size == 0 || (poly_size & (poly_size - 1))) throw std::logic_error("assertion failed: poly_size.is_power_of_two()");
+    MultilinearZipParams pp;
+    pp.num_vars = ilog2(poly_size);
+    pp.num_rows = (uint32_t)next_pow2((1ULL << pp.num_vars) / code.row_len);  // structs.rs:82
+    pp.linear_code = code;
+    // The shim's job: expand the two seeds once (the reference re-runs the shuffle for every row).
+    pp.perm1 = shuffle_seeded_perm(code.perm_1_seed, code.codeword_len());
+    pp.perm2 = shuffle_seeded_perm(code.perm_2_seed, code.codeword_len());
+    zip_params zp{};
+    zp.num_vars = pp.num_vars;
+    zp.row_len = code.row_len;
+    zp.num_rows = pp.num_rows;
+    zp.codeword_len = code.codeword_len();
+    zp.rep = code.repetition_factor;
+    zp.n_limbs = 1;
+    zp.k_limbs = 4;
+    zp.m_limbs = 8;
+    zp.perm1 = pp.perm1.data();
+    zp.perm2 = pp.perm2.data();
+    zp.device = device;
+    zip_ctx *ctx = nullptr;
+    check(nullptr, zip_ctx_create(&zp, &ctx), "zip_ctx_create");
+    pp.ctx = std::shared_ptr<zip_ctx>(ctx, zip_ctx_destroy);
+    return pp;
+}
+
+// validate_input (pcs/utils.rs:24-58)
+static void validate_input(const char *function, uint32_t param_num_vars, uint32_t poly_num_vars, const size_t *point_len) {
+    if (param_num_vars < poly_num_vars)
+        throw ZipError(ZipError::InvalidPcsParam, std::string("Too many variates of poly to ") + function +
+                                                      " (param supports variates up to " + std::to_string(param_num_vars) +
+                                                      " but got " + std::to_string(poly_num_vars) + ")");
+    if (point_len && *point_len != poly_num_vars)
+        throw ZipError(ZipError::InvalidPcsParam, "Invalid point (expect point to have " + std::to_string(poly_num_vars) +
+                                                      " variates but got " + std::to_string(*point_len) + ")");
+}
+
+static std::pair<MultilinearZipData, MultilinearZipCommitment> commit_impl(const MultilinearZipParams &pp,
+                                                                          const int64_t *evals, size_t n_evals,
+                                                                          uint32_t poly_num_vars, bool merkle) {
+    validate_input("commit", pp.num_vars, poly_num_vars, nullptr);
+    MultilinearZipCommitment comm;
+    if (merkle) comm.roots.resize(pp.num_rows);
+    zip_commitment *h = nullptr;
+    check(pp.ctx.get(),
+          zip_commit(pp.ctx.get(), evals, n_evals, ZIP_MEM_HOST, merkle ? 1 : 0,
+                     merkle ? reinterpret_cast<uint8_t *>(comm.roots.data()) : nullptr, &h),
+          "zip_commit");
+    MultilinearZipData data;
+    data.handle = std::shared_ptr<zip_commitment>(h, zip_commitment_free);
+    return {std::move(data), std::move(comm)};
+}
+
+std::pair<MultilinearZipData, MultilinearZipCommitment> MultilinearZip::commit(const MultilinearZipParams &pp,
+                                                                               const int64_t *evals, size_t n_evals,
+                                                                               uint32_t poly_num_vars) {
+    return commit_impl(pp, evals, n_evals, poly_num_vars, true);
+}
+
+MultilinearZipData MultilinearZip::commit_no_merkle(const MultilinearZipParams &pp, const int64_t *evals, size_t n_evals,
+                                                    uint32_t poly_num_vars) {
+    return commit_impl(pp, evals, n_evals, poly_num_vars, false).first;
+}
+
+void MultilinearZip::open(const MultilinearZipParams &pp, const int64_t *evals, size_t n_evals, uint32_t poly_num_vars,
+                          const MultilinearZipData &commit_data, const Limbs *point, size_t point_len,
+                          const FieldConfig &field, PcsTranscript &transcript) {
+    validate_input("open", pp.num_vars, poly_num_vars, &point_len);
+    const uint32_t row_len = pp.linear_code.row_len, num_rows = pp.num_rows, cw = pp.linear_code.codeword_len();
+    if (n_evals != (size_t)row_len * num_rows) throw std::logic_error("evaluations do not fill the matrix");
+    zip_ctx *ctx = pp.ctx.get();
+
+    // ---- everything the transcript yields BEFORE the first absorb (write_integers and
+    // write_merkle_proof never absorb: pcs_transcript.rs:115-135,198-211), in the reference's order
+    std::vector<int64_t> coeffs;
+    if (num_rows > 1) {  // prove_testing_phase, open_z.rs:100-113 (num_proximity_testing == 1 on this path)
+        if (pp.linear_code.num_proximity_testing != 1)
+            throw ZipError(ZipError::InvalidPcsParam, "only one proximity test is supported on the device path");
+        coeffs = transcript.fs_transcript.get_integer_challenges_i64(num_rows);
+    }
+    std::vector<uint32_t> cols(pp.linear_code.num_column_opening);
+    for (auto &c : cols) c = (uint32_t)transcript.squeeze_challenge_idx(field, cw);  // open_z.rs:116-120
+    // left_point_to_tensor (pcs/utils.rs:279-292): eq over the LAST log2(num_rows) coordinates
+    std::vector<uint64_t> q0;
+    if (num_rows > 1) {
+        const uint32_t lr = ilog2(num_rows);
+        const auto eq = build_eq_x_r(field, point + (point_len - lr), lr);
+        q0.resize((size_t)num_rows * field.limbs);
+        for (uint32_t r = 0; r < num_rows; r++)
+            for (uint32_t k = 0; k < field.limbs; k++) q0[(size_t)r * field.limbs + k] = eq[r][k];
+    }
+    // ---- one device call produces the whole stream of open() ----
+    const zip_field zf = field.to_abi();
+    const size_t len = zip_proof_len(ctx, (uint32_t)cols.size(), field.limbs);
+    const size_t at = transcript.stream.size();
+    transcript.stream.resize(at + len);
+    check(ctx,
+          zip_open(commit_data.handle.get(), evals, ZIP_MEM_HOST, coeffs.empty() ? nullptr : coeffs.data(), cols.data(),
+                   (uint32_t)cols.size(), q0.empty() ? nullptr : q0.data(), &zf, transcript.stream.data() + at,
+                   ZIP_MEM_HOST),
+          "zip_open");
+    // ---- write_field_elements absorbs each element of the evaluation row (pcs_transcript.rs:107-113);
+    // the bytes are already in the stream, only the Fiat-Shamir state still has to follow
+    const uint8_t *row_be = transcript.stream.data() + at + len - (size_t)row_len * field.limbs * 8;
+    for (uint32_t c = 0; c < row_len; c++) {
+        Limbs v{};
+        const uint8_t *b = row_be + (size_t)c * field.limbs * 8;
+        for (uint32_t i = 0; i < field.limbs; i++) {
+            uint64_t w = 0;
+            for (int k = 0; k < 8; k++) w = (w << 8) | b[8 * (field.limbs - 1 - i) + k];
+            v[i] = w;
+        }
+        transcript.fs_transcript.absorb_random_field(field, v);
+    }
+}
+
+}  // namespace zip
+}  // namespace zinc

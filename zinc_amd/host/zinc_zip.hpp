@@ -1,0 +1,187 @@
+// zinc_zip.hpp -- C++ mirror of the host side of zinc::zip for the commit/open path.
+//
+// In the real integration this layer is the Rust crate itself: `ZincProver` keeps calling
+// `MultilinearZip::{setup, commit, open}` and a shim inside those functions calls the C ABI of
+// libzip_hip.so.  This image has no Rust toolchain, so the same host logic is
+// restated here in C++ with the reference's names, argument meaning and error behaviour:
+//
+//   zinc::KeccakTranscript          src/transcript.rs
+//   zinc::FieldConfig / FieldElem   src/field/config.rs, src/field.rs (RandomField::Initialized)
+//   zinc::map_to_field              src/conversion.rs:86-100, src/field.rs:536-568
+//   zinc::build_eq_x_r              src/sumcheck/utils.rs:117-177
+//   zinc::zip::shuffle_seeded       src/zip/utils.rs:139-142 (rand 0.9 restated, PARITY UNPINNED)
+//   zinc::zip::RaaCode              src/zip/code_raa.rs:16-140
+//   zinc::zip::PcsTranscript        src/zip/pcs_transcript.rs
+//   zinc::zip::MultilinearZip       src/zip/pcs/structs.rs, commit.rs, open_z.rs
+//
+// Everything sequential and tiny stays here on the host (Fiat-Shamir, permutation expansion,
+// the eq tensor, absorbing the evaluation row); every O(n) loop is a call into the HIP library.
+// There is no CPU implementation of commit/open in this layer.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "zip_hip.h"
+
+namespace zinc {
+
+constexpr uint32_t kMaxLimbs = 8;
+using Limbs = std::array<uint64_t, kMaxLimbs>;  // little-endian, unused limbs zero
+
+// ---------------------------------------------------------------------------- errors
+// zip::Error (src/zip.rs:29-41).  Where the reference panics, this layer throws std::logic_error.
+struct ZipError : std::runtime_error {
+    enum Kind { InvalidPcsParam, InvalidPcsOpen, Transcript, Device } kind;
+    ZipError(Kind k, const std::string &what) : std::runtime_error(what), kind(k) {}
+};
+
+// ---------------------------------------------------------------------------- Keccak-256
+class Keccak256 {
+  public:
+    Keccak256() { std::memset(st_, 0, sizeof st_); }
+    void update(const uint8_t *data, size_t len);
+    void update(std::initializer_list<uint8_t> bytes) { update(bytes.begin(), bytes.size()); }
+    std::array<uint8_t, 32> finalize() const;  // of a clone: the hasher keeps absorbing
+
+  private:
+    static void permute(uint64_t st[25]);
+    void absorb_block(const uint8_t *blk);
+    uint64_t st_[25];
+    uint8_t buf_[136];
+    uint32_t buflen_ = 0;
+};
+
+// ---------------------------------------------------------------------------- field
+// FieldConfig (src/field/config.rs:30-50): Montgomery constants for an odd modulus of `limbs` limbs.
+struct FieldConfig {
+    uint32_t limbs = 0;
+    Limbs modulus{}, r{}, r2{};
+    uint64_t inv = 0;
+    bool modulus_has_spare_bit = false;
+
+    static FieldConfig make(const uint64_t *modulus, uint32_t limbs);  // Config::new, config.rs:174-186
+    void mul_assign(Limbs &a, const Limbs &b) const;                   // config.rs:163-170
+    void add_assign(Limbs &a, const Limbs &b) const;                   // config.rs:53-58
+    void sub_assign(Limbs &a, const Limbs &b) const;                   // config.rs:60-66
+    void neg(Limbs &a) const;                                          // arithmetic.rs:130-149
+    uint32_t num_bits() const;
+    zip_field to_abi() const;
+
+  private:
+    void reduce_modulus(Limbs &a, bool carry) const;  // config.rs:68-76
+};
+
+// FieldMap for i64 / u128 (conversion.rs:9-46,86-100; field.rs:536-568): Montgomery form.
+Limbs map_to_field(const FieldConfig &f, int64_t v);
+Limbs map_to_field_u128(const FieldConfig &f, uint64_t lo, uint64_t hi);
+// build_eq_x_r_vec (sumcheck/utils.rs:117-177); r: nvars field elements, result 2^nvars.
+std::vector<Limbs> build_eq_x_r(const FieldConfig &f, const Limbs *r, uint32_t nvars);
+
+// ---------------------------------------------------------------------------- Fiat-Shamir
+class KeccakTranscript {
+  public:
+    void absorb(const uint8_t *v, size_t len) { hasher_.update(v, len); }
+    std::vector<uint8_t> get_random_bytes(size_t length);          // transcript.rs:40-55
+    void absorb_random_field(const FieldConfig &f, const Limbs &v);  // field.rs:360-378 (Initialized)
+    Limbs get_challenge(const FieldConfig &f);                     // transcript.rs:88-133
+    void get_integer_challenge(uint32_t n_limbs, uint64_t *out);   // transcript.rs:142-155
+    std::vector<int64_t> get_integer_challenges_i64(size_t n);     // transcript.rs:158-160 with I = Int<1>
+    uint64_t get_u64() {                                           // ZipTranscript::get_u64, transcript.rs:183-185
+        uint64_t w;
+        get_integer_challenge(1, &w);
+        return w;
+    }
+
+  private:
+    Keccak256 hasher_;
+};
+
+namespace zip {
+
+// shuffle_seeded applied to the identity: shuffle_seeded(x, seed)[j] == x[perm[j]].
+std::vector<uint32_t> shuffle_seeded_perm(uint64_t seed, uint32_t len);
+
+// LinearCodeSpec / DefaultLinearCodeSpec (src/zip/code.rs:217-242)
+struct LinearCodeSpec {
+    uint32_t num_column_opening = 1000;
+    uint32_t repetition_factor = 2;
+    uint32_t num_proximity_testing = 1;
+};
+
+// A source of permutation seeds: ZipTranscript::get_u64 (structs.rs:67-76).
+struct SeedSource {
+    virtual ~SeedSource() = default;
+    virtual uint64_t get_u64() = 0;
+};
+struct KeccakSeedSource : SeedSource {
+    explicit KeccakSeedSource(KeccakTranscript &t) : t_(t) {}
+    uint64_t get_u64() override { return t_.get_u64(); }
+    KeccakTranscript &t_;
+};
+struct MockTranscript : SeedSource {  // src/zip/pcs/tests.rs:24-37
+    int64_t counter = 0;
+    uint64_t get_u64() override { return (uint64_t)++counter; }
+};
+
+// RaaCode (src/zip/code_raa.rs:16-86), ZipTypes fixed to INT_LIMBS = 1 (N = Int<1>, K = Int<4>, M = Int<8>).
+struct RaaCode {
+    uint32_t row_len = 0, repetition_factor = 0, num_column_opening = 0, num_proximity_testing = 0;
+    uint64_t perm_1_seed = 0, perm_2_seed = 0;
+
+    // RaaCode::new: geometry, width assertion (throws std::logic_error like the reference's assert!),
+    // then two seeds from the transcript.
+    static RaaCode make(const LinearCodeSpec &spec, uint64_t poly_size, SeedSource &transcript);
+    uint32_t codeword_len() const { return row_len * repetition_factor; }
+};
+
+// PcsTranscript (src/zip/pcs_transcript.rs:19-48): Fiat-Shamir state + the proof byte stream.
+struct PcsTranscript {
+    KeccakTranscript fs_transcript;
+    std::vector<uint8_t> stream;
+
+    void write_field_elements(const FieldConfig &f, const Limbs *elems, size_t n);  // :76-113
+    void append(const uint8_t *bytes, size_t n) { stream.insert(stream.end(), bytes, bytes + n); }
+    size_t squeeze_challenge_idx(const FieldConfig &f, size_t cap);                // :174-179
+    std::vector<uint8_t> into_proof() { return std::move(stream); }
+};
+
+// MultilinearZipParams (structs.rs:13-18) + the device context that serves this geometry.
+struct MultilinearZipParams {
+    uint32_t num_vars = 0, num_rows = 0;
+    RaaCode linear_code;
+    std::vector<uint32_t> perm1, perm2;
+    std::shared_ptr<zip_ctx> ctx;  // created by setup()
+};
+
+// MultilinearZipData (structs.rs:33-38): rows + Merkle trees, device resident behind the handle.
+struct MultilinearZipData {
+    std::shared_ptr<zip_commitment> handle;
+};
+// MultilinearZipCommitment (structs.rs:42-45)
+struct MultilinearZipCommitment {
+    std::vector<std::array<uint8_t, 32>> roots;
+};
+
+struct MultilinearZip {
+    // structs.rs:79-91
+    static MultilinearZipParams setup(uint64_t poly_size, const RaaCode &code, int device = 0);
+    // commit.rs:50-87.  poly_num_vars is DenseMultilinearExtension::num_vars of the caller's polynomial.
+    static std::pair<MultilinearZipData, MultilinearZipCommitment> commit(const MultilinearZipParams &pp,
+                                                                          const int64_t *evals, size_t n_evals,
+                                                                          uint32_t poly_num_vars);
+    // commit.rs:104-119
+    static MultilinearZipData commit_no_merkle(const MultilinearZipParams &pp, const int64_t *evals, size_t n_evals,
+                                               uint32_t poly_num_vars);
+    // open_z.rs:22-40.  point: num_vars field elements in Montgomery form.
+    static void open(const MultilinearZipParams &pp, const int64_t *evals, size_t n_evals, uint32_t poly_num_vars,
+                     const MultilinearZipData &commit_data, const Limbs *point, size_t point_len,
+                     const FieldConfig &field, PcsTranscript &transcript);
+};
+
+}  // namespace zip
+}  // namespace zinc

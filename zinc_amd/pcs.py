@@ -1,0 +1,246 @@
+"""ctypes binding of libzinc_zip.so (include/zinc_zip_host.h): the C++ mirror of the host side of
+zinc::zip -- KeccakTranscript, RaaCode::new, MultilinearZip::{setup, commit, open}, PcsTranscript --
+driving the HIP library.  Names and argument meaning follow the reference (src/zip/pcs/*.rs)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import cabi
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libzinc_zip.so")
+OK, ERR_INVALID_PARAM, ERR_PANIC, ERR_DEVICE, ERR_NULL = 0, -1, -2, -3, -4
+
+EXPORTED_SYMBOLS = (
+    "zinc_last_error", "zinc_transcript_new", "zinc_transcript_free", "zinc_transcript_absorb",
+    "zinc_transcript_get_u64", "zinc_transcript_get_integer_challenges", "zinc_transcript_get_challenge",
+    "zinc_field_constants", "zinc_field_mul", "zinc_map_to_field_i64", "zinc_build_eq_x_r",
+    "zinc_shuffle_seeded_perm", "zinc_raa_code_new", "zinc_zip_setup", "zinc_zip_params_free",
+    "zinc_zip_params_geometry", "zinc_zip_commit", "zinc_zip_data_free", "zinc_pcs_transcript_new",
+    "zinc_pcs_transcript_free", "zinc_pcs_transcript_len", "zinc_pcs_transcript_copy",
+    "zinc_pcs_transcript_probe", "zinc_zip_open",
+)
+
+
+class InvalidPcsParam(ValueError):
+    """zip::Error::InvalidPcsParam"""
+
+
+class ReferencePanic(AssertionError):
+    """A place where the reference panics (assert! / expect)."""
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+class RaaCodeStruct(C.Structure):
+    _fields_ = [("row_len", C.c_uint32), ("repetition_factor", C.c_uint32), ("num_column_opening", C.c_uint32),
+                ("num_proximity_testing", C.c_uint32), ("perm_1_seed", C.c_uint64), ("perm_2_seed", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        cabi.lib()  # loads torch's HIP runtime first, then libzip_hip.so
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m zinc_amd.build`")
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.zinc_last_error.restype = C.c_char_p
+        L.zinc_transcript_new.restype = vp
+        L.zinc_transcript_free.argtypes = [vp]
+        L.zinc_transcript_absorb.argtypes = [vp, C.c_char_p, C.c_size_t]
+        L.zinc_transcript_get_u64.argtypes = [vp]
+        L.zinc_transcript_get_u64.restype = C.c_uint64
+        L.zinc_transcript_get_integer_challenges.argtypes = [vp, C.c_size_t, vp]
+        L.zinc_transcript_get_challenge.argtypes = [vp, vp, C.c_uint32, vp]
+        L.zinc_field_constants.argtypes = [vp, C.c_uint32, vp, vp, vp]
+        L.zinc_field_mul.argtypes = [vp, C.c_uint32, vp, vp, vp]
+        L.zinc_map_to_field_i64.argtypes = [vp, C.c_uint32, vp, C.c_size_t, vp]
+        L.zinc_build_eq_x_r.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp]
+        L.zinc_shuffle_seeded_perm.argtypes = [C.c_uint64, C.c_uint32, vp]
+        L.zinc_shuffle_seeded_perm.restype = None
+        L.zinc_raa_code_new.argtypes = [C.c_uint64, vp, C.POINTER(RaaCodeStruct)]
+        L.zinc_zip_setup.argtypes = [C.c_uint64, C.POINTER(RaaCodeStruct), C.c_int32, C.POINTER(vp)]
+        L.zinc_zip_params_free.argtypes = [vp]
+        L.zinc_zip_params_geometry.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 4
+        L.zinc_zip_commit.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_int32, vp, C.POINTER(vp)]
+        L.zinc_zip_data_free.argtypes = [vp]
+        L.zinc_pcs_transcript_new.restype = vp
+        L.zinc_pcs_transcript_free.argtypes = [vp]
+        L.zinc_pcs_transcript_len.argtypes = [vp]
+        L.zinc_pcs_transcript_len.restype = C.c_size_t
+        L.zinc_pcs_transcript_copy.argtypes = [vp, vp]
+        L.zinc_pcs_transcript_probe.argtypes = [vp]
+        L.zinc_pcs_transcript_probe.restype = C.c_uint64
+        L.zinc_zip_open.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp, vp, C.c_size_t, vp, C.c_uint32, vp]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc == OK:
+        return
+    msg = lib().zinc_last_error().decode()
+    if rc == ERR_INVALID_PARAM:
+        raise InvalidPcsParam(msg)
+    if rc == ERR_PANIC:
+        raise ReferencePanic(msg)
+    raise DeviceError(msg)
+
+
+def _limbs(value: int, n: int) -> np.ndarray:
+    return np.array([(value >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)], dtype=np.uint64)
+
+
+class FieldConfig:
+    """FieldConfig::new(modulus) with FIELD_LIMBS = limbs."""
+
+    def __init__(self, modulus: int, limbs: int):
+        self.modulus, self.limbs = modulus, limbs
+        self._m = _limbs(modulus, limbs)
+
+    def constants(self):
+        r, r2 = np.zeros(self.limbs, np.uint64), np.zeros(self.limbs, np.uint64)
+        inv = C.c_uint64()
+        _check(lib().zinc_field_constants(self._m.ctypes.data, self.limbs, r.ctypes.data, r2.ctypes.data, C.byref(inv)))
+        return r, r2, inv.value
+
+    def mul(self, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        out = np.zeros(self.limbs, np.uint64)
+        a, b = np.ascontiguousarray(a, np.uint64), np.ascontiguousarray(b, np.uint64)
+        _check(lib().zinc_field_mul(self._m.ctypes.data, self.limbs, a.ctypes.data, b.ctypes.data, out.ctypes.data))
+        return out
+
+    def map_to_field(self, values) -> np.ndarray:
+        v = np.ascontiguousarray(values, dtype=np.int64)
+        out = np.zeros((v.size, self.limbs), np.uint64)
+        _check(lib().zinc_map_to_field_i64(self._m.ctypes.data, self.limbs, v.ctypes.data, v.size, out.ctypes.data))
+        return out
+
+    def build_eq_x_r(self, r: np.ndarray) -> np.ndarray:
+        r = np.ascontiguousarray(r, np.uint64)
+        out = np.zeros((1 << r.shape[0], self.limbs), np.uint64)
+        _check(lib().zinc_build_eq_x_r(self._m.ctypes.data, self.limbs, r.ctypes.data, r.shape[0], out.ctypes.data))
+        return out
+
+
+class KeccakTranscript:
+    def __init__(self):
+        self._h = lib().zinc_transcript_new()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().zinc_transcript_free(self._h)
+            self._h = None
+
+    def absorb(self, data: bytes):
+        lib().zinc_transcript_absorb(self._h, data, len(data))
+
+    def get_u64(self) -> int:
+        return lib().zinc_transcript_get_u64(self._h)
+
+    def get_integer_challenges(self, n: int) -> np.ndarray:
+        out = np.zeros(n, np.int64)
+        lib().zinc_transcript_get_integer_challenges(self._h, n, out.ctypes.data)
+        return out
+
+    def get_challenge(self, field: FieldConfig) -> np.ndarray:
+        out = np.zeros(field.limbs, np.uint64)
+        _check(lib().zinc_transcript_get_challenge(self._h, field._m.ctypes.data, field.limbs, out.ctypes.data))
+        return out
+
+
+def shuffle_seeded_perm(seed: int, length: int) -> np.ndarray:
+    out = np.zeros(length, np.uint32)
+    lib().zinc_shuffle_seeded_perm(seed, length, out.ctypes.data)
+    return out
+
+
+class RaaCode:
+    """RaaCode::new(&DefaultLinearCodeSpec, poly_size, transcript); transcript=None -> MockTranscript."""
+
+    def __init__(self, poly_size: int, transcript: KeccakTranscript = None):
+        self.s = RaaCodeStruct()
+        _check(lib().zinc_raa_code_new(poly_size, transcript._h if transcript else None, C.byref(self.s)))
+        self.poly_size = poly_size
+
+    row_len = property(lambda self: self.s.row_len)
+    perm_1_seed = property(lambda self: self.s.perm_1_seed)
+    perm_2_seed = property(lambda self: self.s.perm_2_seed)
+
+    def codeword_len(self):
+        return self.s.row_len * self.s.repetition_factor
+
+
+class PcsTranscript:
+    def __init__(self):
+        self._h = lib().zinc_pcs_transcript_new()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().zinc_pcs_transcript_free(self._h)
+            self._h = None
+
+    def into_proof(self) -> np.ndarray:
+        out = np.zeros(lib().zinc_pcs_transcript_len(self._h), np.uint8)
+        if out.size:
+            lib().zinc_pcs_transcript_copy(self._h, out.ctypes.data)
+        return out
+
+    def probe(self) -> int:
+        return lib().zinc_pcs_transcript_probe(self._h)
+
+
+class MultilinearZipData:
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().zinc_zip_data_free(self._h)
+            self._h = None
+
+
+class MultilinearZipParams:
+    def __init__(self, handle):
+        self._h = handle
+        g = [C.c_uint32() for _ in range(4)]
+        lib().zinc_zip_params_geometry(handle, *[C.byref(x) for x in g])
+        self.num_vars, self.num_rows, self.row_len, self.codeword_len = [x.value for x in g]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().zinc_zip_params_free(self._h)
+            self._h = None
+
+
+class MultilinearZip:
+    @staticmethod
+    def setup(poly_size: int, linear_code: RaaCode, device: int = 0) -> MultilinearZipParams:
+        h = C.c_void_p()
+        _check(lib().zinc_zip_setup(poly_size, C.byref(linear_code.s), device, C.byref(h)))
+        return MultilinearZipParams(h)
+
+    @staticmethod
+    def commit(pp: MultilinearZipParams, evaluations, num_vars: int = None, with_merkle: bool = True):
+        ev = np.ascontiguousarray(evaluations, dtype=np.int64)
+        nv = num_vars if num_vars is not None else max(ev.size, 1).bit_length() - 1
+        roots = np.zeros((pp.num_rows, 32), np.uint8)
+        h = C.c_void_p()
+        _check(lib().zinc_zip_commit(pp._h, ev.ctypes.data, ev.size, nv, int(with_merkle), roots.ctypes.data, C.byref(h)))
+        return MultilinearZipData(h), (roots if with_merkle else None)
+
+    @staticmethod
+    def open(pp: MultilinearZipParams, evaluations, commit_data: MultilinearZipData, point: np.ndarray,
+             field: FieldConfig, transcript: PcsTranscript, num_vars: int = None):
+        ev = np.ascontiguousarray(evaluations, dtype=np.int64)
+        nv = num_vars if num_vars is not None else max(ev.size, 1).bit_length() - 1
+        pt = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, field.limbs) if np.size(point) else np.zeros((0, field.limbs), np.uint64)
+        _check(lib().zinc_zip_open(pp._h, ev.ctypes.data, ev.size, nv, commit_data._h, pt.ctypes.data, pt.shape[0],
+                                   field._m.ctypes.data, field.limbs, transcript._h))
