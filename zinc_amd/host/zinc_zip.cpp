@@ -555,6 +555,7 @@ static std::pair<MultilinearZipData, MultilinearZipCommitment> commit_impl(const
                      merkle ? reinterpret_cast<uint8_t *>(comm.roots.data()) : nullptr, &h),
           "zip_commit");
     MultilinearZipData data;
+    data.ctx = pp.ctx;
     data.handle = std::shared_ptr<zip_commitment>(h, zip_commitment_free);
     return {std::move(data), std::move(comm)};
 }

@@ -160,6 +160,7 @@ struct MultilinearZipParams {
 
 // MultilinearZipData (structs.rs:33-38): rows + Merkle trees, device resident behind the handle.
 struct MultilinearZipData {
+    std::shared_ptr<zip_ctx> ctx;             // keeps the device context alive (declared first: destroyed last)
     std::shared_ptr<zip_commitment> handle;
 };
 // MultilinearZipCommitment (structs.rs:42-45)
