@@ -1087,21 +1087,48 @@ int orc_verify(const orc_params *p, const orc_field *f, const uint8_t *roots,
         }
         /* ColumnOpening::verify_column, pcs/utils.rs:235-249.  The reference discards
          * the result (verify_z.rs:99) and stops reading the column's remaining proofs
-         * at the first failure; check_merkle=1 turns a failure into a rejection. */
-        for (uint32_t r = 0; r < R && rc == ORC_OK; r++) {
-            const uint8_t *lb = rs_read(&rs, 8);
-            if (!lb) { rc = ORC_ERR_TRANSCRIPT; break; }
-            uint64_t plen = 0;
-            for (int k = 0; k < 8; k++) plen = (plen << 8) | lb[k];
-            if (plen > 64) { rc = ORC_ERR_TRANSCRIPT; break; }
-            const uint8_t *path = rs_read(&rs, 32 * (size_t)plen);
-            if (!path) { rc = ORC_ERR_TRANSCRIPT; break; }
-            int ok = orc_merkle_verify((uint32_t)plen, path, roots + 32 * (size_t)r,
-                                       cv + (size_t)K * r, K, col) == ORC_OK;
-            if (!ok) {
-                if (check_merkle) rc = ORC_ERR_PROOF;
-                break;
+         * at the first failure; check_merkle=1 turns a failure into a rejection.  The
+         * stream is consumed sequentially; the hashing of a column is spread over threads. */
+        {
+            const uint8_t **paths = (const uint8_t **)malloc(sizeof(uint8_t *) * R);
+            uint64_t *plens = (uint64_t *)malloc(8 * (size_t)R);
+            uint32_t nread = 0;
+            for (uint32_t r = 0; r < R && rc == ORC_OK; r++) {
+                const uint8_t *lb = rs_read(&rs, 8);
+                if (!lb) { rc = ORC_ERR_TRANSCRIPT; break; }
+                uint64_t plen = 0;
+                for (int k = 0; k < 8; k++) plen = (plen << 8) | lb[k];
+                if (plen > 64) { rc = ORC_ERR_TRANSCRIPT; break; }
+                const uint8_t *path = rs_read(&rs, 32 * (size_t)plen);
+                if (!path) { rc = ORC_ERR_TRANSCRIPT; break; }
+                paths[r] = path;
+                plens[r] = plen;
+                nread = r + 1;
             }
+            if (rc == ORC_OK) {
+                int64_t first_bad = -1;
+#pragma omp parallel for schedule(static)
+                for (uint32_t r = 0; r < nread; r++) {
+                    if (orc_merkle_verify((uint32_t)plens[r], paths[r], roots + 32 * (size_t)r, cv + (size_t)K * r, K,
+                                          col) != ORC_OK) {
+#pragma omp critical
+                        if (first_bad < 0 || (int64_t)r < first_bad) first_bad = r;
+                    }
+                }
+                if (first_bad >= 0) {
+                    if (check_merkle) {
+                        rc = ORC_ERR_PROOF;
+                    } else {
+                        /* faithful mode: the reference returns from verify_column at the first bad
+                         * path, leaving the rest of this column's proofs unread in the stream */
+                        size_t unread = 0;
+                        for (uint32_t r = (uint32_t)first_bad + 1; r < nread; r++) unread += 8 + 32 * (size_t)plens[r];
+                        rs.pos -= unread;
+                    }
+                }
+            }
+            free(paths);
+            free(plens);
         }
     }
 

@@ -1,0 +1,102 @@
+"""BASELINE.json's full sizes on the GPU, checked through size-independent properties and sampled
+rows (the oracle cannot redo 2^24 in test time): sampled encoded rows / trees / roots against the
+oracle, exact proof length, the oracle's verifier accepting the 1.74 GiB proof, linearity."""
+import numpy as np
+import pytest
+
+import _oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+BENCH_MODULUS = 106319353542452952636349991594949358997917625194731877894581586278529202198383
+
+
+@pytest.fixture(scope="module")
+def env():
+    torch = pytest.importorskip("torch")
+    from zinc_amd import cabi
+
+    if cabi.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu tests must run on the MI355X box")
+    return cabi, torch
+
+
+def _dev_view(torch, ptr, shape, typestr):
+    h = type("_H", (), {})()
+    h.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+    return torch.as_tensor(h, device="cuda")
+
+
+def _check_sampled_rows(z, evals, rows_t, layers_t, roots, sample):
+    for r in sample:
+        rc, enc = z.encode_row(evals[r * z.row_len:(r + 1) * z.row_len])
+        assert rc == 0
+        assert np.array_equal(rows_t[r].cpu().numpy().view(np.uint64).reshape(z.codeword_len, 4), enc), r
+        tree = orc.merkle_tree(z.depth, enc)
+        got = layers_t[r].cpu().numpy().reshape(2 * z.codeword_len, 32)
+        assert np.array_equal(got[: 2 * z.codeword_len - 1], tree), r  # root included at slot 2cw-2
+        assert np.array_equal(roots[r], tree[-1]), r
+
+
+def test_commit_open_2pow24(env):
+    """configs[2]: commit + open at 2^24 (row_len = num_rows = 4096, codeword 8192, depth 13)."""
+    cabi, torch = env
+    nv = 24
+    z = orc.Zip(nv)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    evals = orc.splitmix64(0x5A494E43, 1 << nv)
+    ctx = cabi.ZipContext(nv, z.perm1, z.perm2)
+    d_evals = torch.from_numpy(evals).cuda()
+    com, roots = ctx.commit(d_evals)
+    rows_p, layers_p, _ = com.device_ptrs()
+    ctx.synchronize()
+    rows_t = _dev_view(torch, rows_p, (z.num_rows, z.codeword_len * 4), "<i8")
+    layers_t = _dev_view(torch, layers_p, (z.num_rows, 2 * z.codeword_len * 32), "|u1")
+    _check_sampled_rows(z, evals, rows_t, layers_t, roots, [0, 1, 255, 256, 2047, 4095, 1234, 3333])
+    # determinism (commit.rs:253-283)
+    com2, roots2 = ctx.commit(d_evals)
+    assert np.array_equal(roots, roots2)
+    com2.free()
+
+    # open with the oracle's Fiat-Shamir stream (fresh PcsTranscript), point = [1; nv] as in the bench
+    point = orc.point_to_field(f, [1] * nv)
+    fs = orc.new_transcript()
+    coeffs = np.zeros(z.num_rows, dtype=np.int64)
+    for r in range(z.num_rows):
+        orc.lib().orc_tr_get_integer_challenge(orc.C.byref(fs), 1, coeffs[r:].ctypes.data_as(orc.C.POINTER(orc.C.c_uint64)))
+    cols = np.array([orc.get_challenge(fs, f) % (1 << 32) % z.codeword_len for _ in range(1000)], dtype=np.uint32)
+    lr = z.num_rows.bit_length() - 1
+    q0 = orc.build_eq_x_r(f, point[nv - lr:])
+    proof = com.open(d_evals, coeffs, cols, q0, cabi.make_field(BENCH_MODULUS, 4))
+    assert proof.size == z.proof_len(4) == 4096 * 64 + 1000 * 4096 * (32 + 8 + 32 * 13) + 4096 * 32  # commit.rs:712-737
+    ev = z.mle_eval(f, evals, point)
+    assert z.verify(f, roots, point, ev, proof, check_merkle=True) == 0
+    bad = proof.copy()
+    bad[proof.size // 2] ^= 1
+    assert z.verify(f, roots, point, ev, bad, check_merkle=True) != 0
+
+    # linearity of the proximity row: unit coefficients select a witness row (combine_rows definition)
+    unit = np.zeros(z.num_rows, dtype=np.int64)
+    unit[777] = 1
+    u = ctx.open_testing(d_evals, unit)
+    w = evals[777 * z.row_len:778 * z.row_len]
+    assert np.array_equal(u[:, 0].view(np.int64), w)
+    assert np.array_equal(u[:, 1:], np.repeat(((w < 0) * np.uint64(0xFFFFFFFFFFFFFFFF)).astype(np.uint64)[:, None], 7, axis=1))
+
+
+def test_commit_2pow26_geometry_sampled(env):
+    """configs[3] geometry (row_len 8192, codeword 16384, depth 14; the variant that parks t2 in the
+    output row), on a 1024-row slice = what one of 8 GPUs owns of a 2^26 commit."""
+    cabi, torch = env
+    nv, rows = 26, 1024
+    zfull = orc.Zip(nv, perm1=np.zeros(1, np.uint32), perm2=np.zeros(1, np.uint32))
+    assert (zfull.row_len, zfull.num_rows, zfull.codeword_len) == (8192, 8192, 16384)
+    z = orc.Zip(nv, geometry=(8192, rows, 16384))
+    evals = orc.splitmix64(26, rows * 8192)
+    ctx = cabi.ZipContext(nv, z.perm1, z.perm2, row_begin=2048, row_count=rows)
+    com, roots = ctx.commit(torch.from_numpy(evals).cuda())
+    rows_p, layers_p, _ = com.device_ptrs()
+    ctx.synchronize()
+    rows_t = _dev_view(torch, rows_p, (rows, z.codeword_len * 4), "<i8")
+    layers_t = _dev_view(torch, layers_p, (rows, 2 * z.codeword_len * 32), "|u1")
+    _check_sampled_rows(z, evals, rows_t, layers_t, roots, [0, 511, 1023])
