@@ -77,6 +77,33 @@ int32_t zinc_zip_open(const zinc_zip_params *pp, const int64_t *evals, size_t n_
                       const zinc_zip_data *data, const uint64_t *point, size_t point_len, const uint64_t *modulus,
                       uint32_t limbs, zinc_pcs_transcript *transcript);
 
+/* PcsTranscript::from_proof (src/zip/pcs_transcript.rs:28-35): the reading side */
+zinc_pcs_transcript *zinc_pcs_transcript_from_proof(const uint8_t *proof, size_t len);
+size_t zinc_pcs_transcript_position(const zinc_pcs_transcript *t);
+
+/* MultilinearZip::verify (src/zip/pcs/verify_z.rs:19-38).  roots: num_rows * 32 bytes; eval: Montgomery limbs.
+ * ZINC_OK = accepted; ZINC_ERR_INVALID_OPEN = rejected (zinc_last_error() carries the reference's message);
+ * ZINC_ERR_PANIC where the reference panics. */
+#define ZINC_ERR_INVALID_OPEN (-5)
+int32_t zinc_zip_verify(const zinc_zip_params *vp, const uint8_t *roots, const uint64_t *point, size_t point_len,
+                        const uint64_t *eval, const uint64_t *modulus, uint32_t limbs, zinc_pcs_transcript *transcript);
+
+/* z_mle.map_to_field(config).evaluate(r_y) (src/zinc/prover.rs:317-319): out = limbs Montgomery limbs */
+int32_t zinc_zip_evaluate(const zinc_zip_params *pp, const int64_t *evals, size_t n_evals, const uint64_t *point,
+                          size_t point_len, const uint64_t *modulus, uint32_t limbs, uint64_t *out);
+
+/* ZincProver::commit_z_mle_and_prove_evaluation (src/zinc/prover.rs:305-327) -> ZipProof {z_comm, v, pcs_proof}.
+ * transcript: the prover's main KeccakTranscript (two permutation seeds are drawn from it).
+ * Call once with proof_out == NULL to learn *proof_len and *n_roots; the result is kept in the handle. */
+typedef struct zinc_zip_proof zinc_zip_proof;
+int32_t zinc_commit_z_mle_and_prove_evaluation(const int64_t *z_evals, size_t m, const uint64_t *r_y, size_t r_y_len,
+                                               zinc_transcript *transcript, const uint64_t *modulus, uint32_t limbs,
+                                               int32_t device, zinc_zip_proof **out);
+size_t zinc_zip_proof_len(const zinc_zip_proof *p);
+size_t zinc_zip_proof_num_roots(const zinc_zip_proof *p);
+void zinc_zip_proof_read(const zinc_zip_proof *p, uint8_t *roots_out, uint64_t *v_out, uint8_t *pcs_proof_out);
+void zinc_zip_proof_free(zinc_zip_proof *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -146,6 +146,54 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
                  const uint32_t *cols, uint32_t n_cols, const uint64_t *q0_mont, const zip_field *field,
                  uint8_t *proof_out, zip_mem_kind out_kind);
 
+/* ---- verifier side ---------------------------------------------
+ * MultilinearZip::verify (src/zip/pcs/verify_z.rs:19-188) on the device.  The caller (the Rust
+ * shim / zinc_amd/host) keeps the Fiat-Shamir work: it squeezes `coeffs` (num_rows, only when
+ * num_rows > 1) and the `cols`, builds (q0, q1) = point_to_tensor (pcs/utils.rs:252-276) and, after
+ * the call, absorbs the row_len field elements at the end of the stream
+ * (read_field_elements, pcs_transcript.rs:138-160).
+ *   roots      HOST, num_rows * 32 bytes (MultilinearZipCommitment.roots)
+ *   proof      the stream `open` wrote, zip_proof_len() bytes (longer is allowed, shorter is malformed)
+ *   q1_mont    row_len field elements (may be NULL when row_len == 1: q_1 is empty there)
+ *   eval_mont  the claimed evaluation, Montgomery limbs
+ * report->verdict is the first check that fails in the reference's order, ZIP_VERIFY_ACCEPT if none.
+ * Deliberate differences from the reference, both on the rejecting side:
+ *  - Merkle paths ARE checked (the reference computes the check and drops the result,
+ *    verify_z.rs:99, but then loses its place in the stream at the first bad path);
+ *  - evaluation-row elements >= q are rejected as malformed (the reference does not range-check
+ *    them; its sequential modular additions then depend on the representation).
+ * The function result is only non-zero for usage / device errors. */
+typedef enum {
+    ZIP_VERIFY_ACCEPT = 0,
+    ZIP_VERIFY_PROXIMITY_TESTING = 1, /* "Proximity failure", verify_z.rs:122-125 */
+    ZIP_VERIFY_EVAL_CONSISTENCY = 2,  /* "Evaluation consistency failure", verify_z.rs:145-149 */
+    ZIP_VERIFY_PROXIMITY_Q0 = 3,      /* "Proximity failure", verify_z.rs:184-186 */
+    ZIP_VERIFY_MERKLE = 4,            /* a path does not hash to its row root */
+    ZIP_VERIFY_MALFORMED = 5,         /* short stream, wrong path length prefix, non-canonical field element */
+    ZIP_VERIFY_OVERFLOW = 6           /* encode_wide overflows Int<M>: the reference panics (int.rs:122-134) */
+} zip_verify_verdict;
+typedef struct {
+    int32_t verdict;
+    uint32_t column;           /* index into cols[] of the failing opening, when the verdict names one */
+    uint32_t bad_merkle_paths; /* over all openings */
+    uint32_t malformed_paths;
+} zip_verify_report;
+int32_t zip_verify(zip_ctx *ctx, const uint8_t *roots, const uint8_t *proof, zip_mem_kind proof_kind, size_t proof_len,
+                   const int64_t *coeffs, const uint32_t *cols, uint32_t n_cols, const uint64_t *q0_mont,
+                   const uint64_t *q1_mont, const uint64_t *eval_mont, const zip_field *field,
+                   zip_verify_report *report);
+
+/* Diagnostic: FieldMap for Int<4> (src/conversion.rs:86-100) of n arbitrary 256-bit values, as the
+ * verifier applies it to column entries.  values: HOST n*4 limbs; out: HOST n*limbs Montgomery limbs. */
+int32_t zip_field_map_int256(zip_ctx *ctx, const uint64_t *values, uint32_t n, const zip_field *field, uint64_t *out);
+
+/* z_mle.map_to_field(config).evaluate(r_y) (src/zinc/prover.rs:317-319, poly_f/mle/dense.rs:35-41),
+ * the step ZincProver runs between commit and open: <q0-combination of the rows, q1>.
+ * q0_mont: num_rows elements (NULL when num_rows == 1), q1_mont: row_len elements (NULL when
+ * row_len == 1).  value_out: HOST, field->limbs Montgomery limbs. */
+int32_t zip_mle_eval(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_kind, const uint64_t *q0_mont,
+                     const uint64_t *q1_mont, const zip_field *field, uint64_t *value_out);
+
 /* Row-sharded open: exact sum of n_parts partial results (after an all-gather).
  * uparts: n_parts * row_len * m_limbs u64 or NULL; fparts: n_parts * row_len * limbs u64 or NULL.
  * All pointers DEVICE memory. */

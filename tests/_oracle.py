@@ -138,6 +138,14 @@ def field_from_i64(f: Field, v: int) -> int:
     return limbs_to_int(out[: f.fl])
 
 
+def field_from_int(f: Field, limbs) -> np.ndarray:
+    """FieldMap for an n-limb two's-complement Int (conversion.rs:86-100): Montgomery limbs."""
+    v = np.ascontiguousarray(limbs, dtype=np.uint64)
+    out = (C.c_uint64 * ORC_MAX_FL)()
+    lib().orc_field_from_int(C.byref(f), _u64p(v), v.size, out)
+    return np.array(out[: f.fl], dtype=np.uint64)
+
+
 def field_mul(f: Field, a: int, b: int) -> int:
     aa = (C.c_uint64 * ORC_MAX_FL)(*int_to_limbs(a, f.fl))
     bb = (C.c_uint64 * ORC_MAX_FL)(*int_to_limbs(b, f.fl))

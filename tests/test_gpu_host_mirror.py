@@ -98,3 +98,61 @@ def test_commit_no_merkle_then_open_fails(pcs):
     field = pcs.FieldConfig(BENCH_MODULUS, 4)
     with pytest.raises(pcs.InvalidPcsParam):
         pcs.MultilinearZip.open(param, evals, data, field.map_to_field([1] * 8), field, pcs.PcsTranscript())
+
+
+@pytest.mark.parametrize("nv,modulus,fl", [(8, TEST_MODULUS_2, 2), (10, BENCH_MODULUS, 4), (13, BENCH_MODULUS, 4)])
+def test_prover_pcs_step_and_verifier_round_trip(pcs, nv, modulus, fl):
+    """ZincProver::commit_z_mle_and_prove_evaluation (zinc/prover.rs:305-327) produces the oracle's
+    ZipProof {z_comm, v, pcs_proof}; MultilinearZip::verify (verify_z.rs:19-38) accepts it, leaves the
+    Fiat-Shamir state where the oracle's verifier leaves it, and rejects it once tampered with."""
+    rng = np.random.default_rng(nv + 100)
+    evals = rng.integers(-128, 128, size=1 << nv, dtype=np.int64) if fl == 2 else orc.splitmix64(nv + 9, 1 << nv)
+    point_i = rng.integers(-128, 128, size=nv, dtype=np.int64)
+    z, fo, roots_o, point, proof_o, probe_o = _oracle_flow(nv, modulus, fl, evals, point_i, b"spartan")
+    v_o = z.mle_eval(fo, evals, point)
+
+    field = pcs.FieldConfig(modulus, fl)
+    transcript = pcs.KeccakTranscript()
+    transcript.absorb(b"spartan")
+    r_y = field.map_to_field(point_i)
+    roots, v, proof = pcs.commit_z_mle_and_prove_evaluation(evals, r_y, transcript, field)
+    assert np.array_equal(roots, roots_o)
+    assert orc.limbs_to_int(v) == v_o
+    assert np.array_equal(proof, proof_o)
+
+    # verifier side: the code comes from the same main-transcript state
+    vt = pcs.KeccakTranscript()
+    vt.absorb(b"spartan")
+    vp = pcs.MultilinearZip.setup(1 << nv, pcs.RaaCode(1 << nv, vt))
+    t = pcs.PcsTranscript.from_proof(proof)
+    pcs.MultilinearZip.verify(vp, roots, r_y, v, field, t)
+    assert t.position() == proof.size
+    fs = orc.new_transcript()
+    assert z.verify(fo, roots_o, point, v_o, proof_o, fs=fs) == 0
+    assert t.probe() == orc.lib().orc_tr_get_u64(orc.C.byref(fs))
+
+    bad = proof.copy()
+    bad[bad.size // 2] ^= 4
+    with pytest.raises(pcs.InvalidPcsOpen):
+        pcs.MultilinearZip.verify(vp, roots, r_y, v, field, pcs.PcsTranscript.from_proof(bad))
+    with pytest.raises(pcs.InvalidPcsOpen, match="Evaluation consistency failure"):
+        wrong = v.copy()
+        wrong[0] ^= np.uint64(1)
+        pcs.MultilinearZip.verify(vp, roots, r_y, wrong, field, pcs.PcsTranscript.from_proof(proof))
+    with pytest.raises(pcs.InvalidPcsOpen):
+        pcs.MultilinearZip.verify(vp, roots, r_y, v, field, pcs.PcsTranscript.from_proof(proof[:-8]))
+    with pytest.raises(pcs.InvalidPcsParam):
+        pcs.MultilinearZip.verify(vp, roots, r_y[:-1], v, field, pcs.PcsTranscript.from_proof(proof))
+
+
+def test_evaluate_matches_map_to_field_then_evaluate(pcs):
+    nv = 9
+    field = pcs.FieldConfig(BENCH_MODULUS, 4)
+    evals = orc.splitmix64(3, 1 << nv)
+    point_i = np.arange(-4, nv - 4, dtype=np.int64)
+    param = pcs.MultilinearZip.setup(1 << nv, pcs.RaaCode(1 << nv))
+    v = pcs.MultilinearZip.evaluate(param, evals, field.map_to_field(point_i), field)
+    fo = orc.make_field(BENCH_MODULUS, 4)
+    assert orc.limbs_to_int(v) == orc.Zip(nv).mle_eval(fo, evals, orc.point_to_field(fo, point_i))
+    with pytest.raises(pcs.InvalidPcsParam):
+        pcs.MultilinearZip.evaluate(param, evals, field.map_to_field(point_i[:-1]), field)

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = (
     "zip_ctx_last_error", "zip_ctx_synchronize", "zip_ctx_stream", "zip_commit", "zip_commitment_free",
     "zip_commitment_device_ptrs", "zip_commit_download", "zip_commitment_upload", "zip_open_testing",
     "zip_open_columns", "zip_open_eval", "zip_proof_len", "zip_open", "zip_sum_partials", "zip_merkle_trees",
-    "zip_ctx_set_profiling", "zip_ctx_profile_read",
+    "zip_ctx_set_profiling", "zip_ctx_profile_read", "zip_verify", "zip_mle_eval", "zip_field_map_int256",
 )
 
 
@@ -50,6 +50,15 @@ class ZipParams(C.Structure):
 
 class ZipField(C.Structure):
     _fields_ = [("limbs", C.c_uint32), ("modulus", C.c_uint64 * 8)]
+
+
+class VerifyReport(C.Structure):
+    _fields_ = [("verdict", C.c_int32), ("column", C.c_uint32), ("bad_merkle_paths", C.c_uint32),
+                ("malformed_paths", C.c_uint32)]
+
+
+VERIFY_ACCEPT, VERIFY_PROXIMITY_TESTING, VERIFY_EVAL_CONSISTENCY, VERIFY_PROXIMITY_Q0 = 0, 1, 2, 3
+VERIFY_MERKLE, VERIFY_MALFORMED, VERIFY_OVERFLOW = 4, 5, 6
 
 
 class KernelTime(C.Structure):
@@ -90,6 +99,10 @@ def lib():
     L.zip_ctx_stream.argtypes = [vp]
     L.zip_ctx_stream.restype = vp
     L.zip_commit.argtypes = [vp, i64p, C.c_size_t, C.c_int, C.c_int32, u8p, C.POINTER(vp)]
+    L.zip_verify.argtypes = [vp, u8p, vp, C.c_int, C.c_size_t, i64p, u32p, C.c_uint32, u64p, u64p, u64p,
+                             C.POINTER(ZipField), C.POINTER(VerifyReport)]
+    L.zip_mle_eval.argtypes = [vp, i64p, C.c_int, u64p, u64p, C.POINTER(ZipField), u64p]
+    L.zip_field_map_int256.argtypes = [vp, u64p, C.c_uint32, C.POINTER(ZipField), u64p]
     L.zip_commitment_free.argtypes = [vp]
     L.zip_commitment_free.restype = None
     L.zip_commitment_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
@@ -108,7 +121,7 @@ def lib():
     for fn in ("zip_ctx_create", "zip_ctx_synchronize", "zip_commit", "zip_commitment_device_ptrs",
                "zip_commit_download", "zip_commitment_upload", "zip_open_testing", "zip_open_columns",
                "zip_open_eval", "zip_open", "zip_sum_partials", "zip_merkle_trees", "zip_ctx_set_profiling",
-               "zip_ctx_profile_read"):
+               "zip_ctx_profile_read", "zip_verify", "zip_mle_eval", "zip_field_map_int256"):
         getattr(L, fn).restype = C.c_int32
     _lib = L
     return L
@@ -249,6 +262,44 @@ class ZipContext:
         optr, okind = _ptr(res)
         self._check(lib().zip_open_eval(self._h, ptr, kind, q0p, C.byref(field), optr, okind), "zip_open_eval")
         return res
+
+    def verify(self, roots, proof, coeffs, cols, q0_mont, q1_mont, eval_mont, field: ZipField):
+        """MultilinearZip::verify on the device; returns the zip_verify_report as a dict."""
+        roots_c = np.ascontiguousarray(roots, dtype=np.uint8)
+        cols_c = np.ascontiguousarray(cols, dtype=np.uint32)
+        coeffs_c = None if coeffs is None else np.ascontiguousarray(coeffs, dtype=np.int64)
+        q0 = None if q0_mont is None else np.ascontiguousarray(q0_mont, dtype=np.uint64)
+        q1 = None if q1_mont is None else np.ascontiguousarray(q1_mont, dtype=np.uint64)
+        ev = np.ascontiguousarray(eval_mont, dtype=np.uint64)
+        if isinstance(proof, np.ndarray):
+            proof = np.ascontiguousarray(proof, dtype=np.uint8)
+        pptr, pkind = _ptr(proof)
+        plen = proof.size if isinstance(proof, np.ndarray) else proof.numel()
+        rep = VerifyReport()
+        rc = lib().zip_verify(self._h, roots_c.ctypes.data, pptr, pkind, plen,
+                              None if coeffs_c is None else coeffs_c.ctypes.data, cols_c.ctypes.data, cols_c.size,
+                              None if q0 is None else q0.ctypes.data, None if q1 is None else q1.ctypes.data,
+                              ev.ctypes.data, C.byref(field), C.byref(rep))
+        self._check(rc, "zip_verify")
+        return {"verdict": rep.verdict, "column": rep.column, "bad_merkle_paths": rep.bad_merkle_paths,
+                "malformed_paths": rep.malformed_paths}
+
+    def mle_eval(self, evals, q0_mont, q1_mont, field: ZipField):
+        ptr, kind = _ptr(evals)
+        q0 = None if q0_mont is None else np.ascontiguousarray(q0_mont, dtype=np.uint64)
+        q1 = None if q1_mont is None else np.ascontiguousarray(q1_mont, dtype=np.uint64)
+        out = np.zeros(field.limbs, dtype=np.uint64)
+        self._check(lib().zip_mle_eval(self._h, ptr, kind, None if q0 is None else q0.ctypes.data,
+                                       None if q1 is None else q1.ctypes.data, C.byref(field), out.ctypes.data),
+                    "zip_mle_eval")
+        return out
+
+    def field_map_int256(self, values, field: ZipField):
+        v = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((v.shape[0], field.limbs), dtype=np.uint64)
+        self._check(lib().zip_field_map_int256(self._h, v.ctypes.data, v.shape[0], C.byref(field), out.ctypes.data),
+                    "zip_field_map_int256")
+        return out
 
     def proof_len(self, n_cols, field_limbs):
         return lib().zip_proof_len(self._h, n_cols, field_limbs)

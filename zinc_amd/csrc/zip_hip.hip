@@ -18,6 +18,7 @@
 #include "../../include/zip_hip.h"
 #include "kernels_commit.cuh"
 #include "kernels_open.cuh"
+#include "kernels_verify.cuh"
 
 using namespace zipk;
 
@@ -59,7 +60,7 @@ struct zip_ctx {
     // pinned host staging for the small per-call inputs (coeffs, q0, column indices): one
     // truly asynchronous H2D copy instead of several pageable (blocking, staged) ones
     unsigned char *pinned_base = nullptr, *stage_h = nullptr, *stage_big = nullptr;
-    size_t stage_cap = 0;
+    size_t stage_cap = 0, stage_big_cap = 0;
     std::string last_error;
     // caching allocator: exact-size free lists
     std::multimap<size_t, void *> free_blocks;
@@ -159,32 +160,37 @@ struct Scratch {
 // buffer.  The staging buffer is reused by the next call, so every caller synchronises the
 // stream before returning (they all do: host inputs must be consumed before we return).
 struct SmallInputs {
-    const void *src[3] = {nullptr, nullptr, nullptr};
-    size_t bytes[3] = {0, 0, 0};
-    size_t off[3] = {0, 0, 0};
+    static constexpr int N = 6;
+    const void *src[N] = {};
+    size_t bytes[N] = {};
+    size_t off[N] = {};
 };
 int32_t stage_small(zip_ctx *ctx, SmallInputs &in, Scratch &dev, unsigned char **base) {
     size_t total = 0;
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < SmallInputs::N; i++) {
         in.off[i] = total;
         total += (in.bytes[i] + 255) & ~(size_t)255;
     }
     if (total == 0) { *base = nullptr; return ZIP_OK; }
+    unsigned char *stage = ctx->stage_h;
     if (total > ctx->stage_cap) {
-        if (ctx->stage_big) (void)hipHostFree(ctx->stage_big);
-    if (ctx->pinned_base) (void)hipHostFree(ctx->pinned_base);
-        ctx->stage_h = nullptr;
-        ctx->stage_cap = 0;
-        size_t cap = total < (1u << 20) ? (1u << 20) : total;
-        hipError_t e = hipHostMalloc((void **)&ctx->stage_h, cap, hipHostMallocDefault);
-        if (e != hipSuccess) return fail(ctx, ZIP_ERR_ALLOC, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
-        ctx->stage_cap = cap;
+        // larger than the block allocated with the ctx (which also holds the timeout flag and
+        // stays where it is): a second pinned buffer, grown on demand
+        if (total > ctx->stage_big_cap) {
+            if (ctx->stage_big) (void)hipHostFree(ctx->stage_big);
+            ctx->stage_big = nullptr;
+            ctx->stage_big_cap = 0;
+            hipError_t e = hipHostMalloc((void **)&ctx->stage_big, total, hipHostMallocDefault);
+            if (e != hipSuccess) return fail(ctx, ZIP_ERR_ALLOC, "hipHostMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+            ctx->stage_big_cap = total;
+        }
+        stage = ctx->stage_big;
     }
-    for (int i = 0; i < 3; i++)
-        if (in.bytes[i]) memcpy(ctx->stage_h + in.off[i], in.src[i], in.bytes[i]);
+    for (int i = 0; i < SmallInputs::N; i++)
+        if (in.bytes[i]) memcpy(stage + in.off[i], in.src[i], in.bytes[i]);
     int32_t rc = dev.get(total);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(dev.ptr, ctx->stage_h, total, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dev.ptr, stage, total, hipMemcpyHostToDevice, ctx->stream));
     *base = dev.as<unsigned char>();
     return ZIP_OK;
 }
@@ -596,6 +602,157 @@ int32_t deliver(zip_ctx *ctx, void *dst, zip_mem_kind kind, const void *src_d, s
     } else if (dst != src_d) {
         HIP_TRY(ctx, hipMemcpyAsync(dst, src_d, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     }
+    return ZIP_OK;
+}
+
+
+// ------------------------------------------------------------------ verifier side
+// Montgomery constants of 2^256 - q, the modulus the reference actually reduces Int<4> column
+// entries by when q has its top bit set in four limbs (field_from_int256 in kernels_verify.cuh).
+bool make_quirk_field(const HostField &hf, HostField *fq) {
+    if (hf.fl != 4 || !(hf.modulus[3] >> 63)) return false;
+    uint64_t m[8] = {0};
+    sub_limbs(m, hf.modulus, 4);  // 2^256 - q (odd, < 2^255)
+    fq->fl = 4;
+    memcpy(fq->modulus, m, 32);
+    uint64_t inv = 1;
+    for (int i = 0; i < 63; i++) {
+        inv *= inv;
+        inv *= m[0];
+    }
+    fq->inv = (uint64_t)0 - inv;
+    // R mod q' and R^2 mod q' by doubling; start from 1 mod q' (q' may be 1: then everything is 0)
+    bool one = m[0] == 1 && !m[1] && !m[2] && !m[3];
+    uint64_t x[8] = {one ? 0ull : 1ull};
+    for (uint32_t i = 0; i < 256; i++) dbl_mod(x, m, 4);
+    memcpy(fq->r, x, 32);
+    for (uint32_t i = 0; i < 256; i++) dbl_mod(x, m, 4);
+    memcpy(fq->r2, x, 32);
+    fq->quirk_mod = 0;
+    return true;
+}
+
+template <int L, bool FIELD>
+int32_t launch_encode_row(zip_ctx *ctx, const uint64_t *in, uint64_t *tmp, uint64_t *out, const FieldDev<L> &fd,
+                          uint32_t *overflow) {
+    const uint32_t cw = ctx->p.codeword_len;
+    const uint32_t threads = cw < 1024 ? (cw < 64 ? 64 : cw) : 1024;
+    const size_t lds = (size_t)threads * sizeof(EncElem<L, FIELD>);
+    auto kern = encode_row_kernel<L, FIELD>;
+    static size_t lds_attr = 0;
+    if (lds > lds_attr) {
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_attr = lds;
+    }
+    LaunchTimer t(ctx, "encode_row_kernel");
+    hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, ctx->stream, in, ctx->p.row_len, cw, ctx->perm1_d,
+                       ctx->perm2_d, tmp, out, fd, overflow);
+    HIP_TRY(ctx, hipGetLastError());
+    return ZIP_OK;
+}
+
+struct VerifyIn {
+    const uint8_t *proof_d;  // device
+    const uint8_t *roots_d;
+    const int64_t *coeffs_d;
+    const uint32_t *cols_d;
+    const uint64_t *q0_d, *q1_d;
+    uint32_t n_cols;
+};
+struct VerifyCounters {  // one device block, copied back in one piece
+    uint32_t overflow, noncanonical, pad[2];
+    uint64_t dot[4];
+};
+
+template <int FL>
+int32_t run_verify_fl(zip_ctx *ctx, const VerifyIn &in, const HostField &hf, std::vector<uint32_t> &flags,
+                      std::vector<uint32_t> &bad, std::vector<uint32_t> &malformed, VerifyCounters *cnt) {
+    const uint32_t R = ctx->p.num_rows, C = ctx->p.row_len, cw = ctx->p.codeword_len, M = ctx->p.m_limbs;
+    const uint32_t n_cols = in.n_cols;
+    const bool single = R == 1;
+    const size_t u_bytes = single ? 0 : (size_t)C * M * 8;
+    const size_t cols_bytes = (size_t)n_cols * column_bytes(ctx);
+    const uint32_t blocks = (R + 255) / 256;
+    Scratch enc_u(ctx), enc_f(ctx), tmp(ctx), row(ctx), parts(ctx), misc(ctx);
+    int32_t rc;
+    if ((rc = enc_u.get((size_t)cw * M * 8))) return rc;
+    if ((rc = enc_f.get((size_t)cw * FL * 8))) return rc;
+    if ((rc = tmp.get((size_t)cw * M * 8))) return rc;
+    if ((rc = row.get((size_t)C * FL * 8))) return rc;
+    if ((rc = parts.get((size_t)n_cols * blocks * (6 + FL) * 8 + 64))) return rc;
+    // misc: counters | flags[n] | bad[n] | malformed[n]
+    const size_t misc_bytes = sizeof(VerifyCounters) + (size_t)3 * n_cols * 4;
+    if ((rc = misc.get(misc_bytes))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(misc.ptr, 0, misc_bytes, ctx->stream));
+    VerifyCounters *cnt_d = misc.as<VerifyCounters>();
+    uint32_t *flags_d = reinterpret_cast<uint32_t *>(cnt_d + 1), *bad_d = flags_d + n_cols, *mal_d = bad_d + n_cols;
+    const FieldDev<FL> fd = to_dev<FL>(hf);
+    FieldDev<FL> fq = fd;
+    bool quirk = false;
+    if constexpr (FL == 4) {
+        HostField hq;
+        quirk = make_quirk_field(hf, &hq);
+        if (quirk) fq = to_dev<4>(hq);
+    }
+    // encode_wide(u') (verify_z.rs:75-77)
+    if (!single) {
+        FieldDev<8> unused{};
+        if ((rc = launch_encode_row<8, false>(ctx, reinterpret_cast<const uint64_t *>(in.proof_d), tmp.as<uint64_t>(),
+                                              enc_u.as<uint64_t>(), unused, &cnt_d->overflow)))
+            return rc;
+    }
+    // read_field_elements + encode_f + <row, q1> (verify_z.rs:139-149)
+    {
+        LaunchTimer t(ctx, "decode_field_row_kernel");
+        hipLaunchKernelGGL(decode_field_row_kernel<FL>, dim3((C + 255) / 256), dim3(256), 0, ctx->stream,
+                           in.proof_d + u_bytes + cols_bytes, C, row.as<uint64_t>(), &cnt_d->noncanonical, fd);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    if ((rc = launch_encode_row<FL, true>(ctx, row.as<uint64_t>(), tmp.as<uint64_t>(), enc_f.as<uint64_t>(), fd, nullptr)))
+        return rc;
+    {
+        LaunchTimer t(ctx, "field_dot_kernel");
+        hipLaunchKernelGGL(field_dot_kernel<FL>, dim3(1), dim3(1024), 0, ctx->stream, row.as<uint64_t>(), in.q1_d, C,
+                           cnt_d->dot, fd);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    if (n_cols) {
+        VerifyColsArgs a{};
+        a.wire = in.proof_d + u_bytes;
+        a.cols = in.cols_d;
+        a.coeffs = single ? nullptr : in.coeffs_d;
+        a.q0 = single ? nullptr : in.q0_d;
+        a.roots = reinterpret_cast<const uint32_t *>(in.roots_d);
+        a.num_rows = R;
+        a.depth = ctx->depth;
+        a.n_cols = n_cols;
+        a.quirk = quirk ? 1u : 0u;
+        a.part_int = parts.as<uint64_t>();
+        a.part_f = a.part_int + (size_t)n_cols * blocks * 6;
+        a.bad_merkle = bad_d;
+        a.malformed = mal_d;
+        {
+            LaunchTimer t(ctx, "verify_columns_kernel");
+            hipLaunchKernelGGL(verify_columns_kernel<FL>, dim3(n_cols, blocks), dim3(256), 0, ctx->stream, a, fd, fq);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        {
+            LaunchTimer t(ctx, "verify_finalize_kernel");
+            hipLaunchKernelGGL(verify_finalize_kernel<FL>, dim3((n_cols + 255) / 256), dim3(256), 0, ctx->stream,
+                               a.part_int, a.part_f, blocks, in.cols_d, n_cols,
+                               single ? nullptr : enc_u.as<uint64_t>(), M, enc_f.as<uint64_t>(), flags_d, fd);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+    }
+    std::vector<unsigned char> host(misc_bytes);
+    HIP_TRY(ctx, hipMemcpyAsync(host.data(), misc.ptr, misc_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(cnt, host.data(), sizeof(VerifyCounters));
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(host.data() + sizeof(VerifyCounters));
+    flags.assign(w, w + n_cols);
+    bad.assign(w + n_cols, w + 2 * n_cols);
+    malformed.assign(w + 2 * n_cols, w + 3 * n_cols);
     return ZIP_OK;
 }
 
@@ -1125,6 +1282,147 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
     if (out_kind == ZIP_MEM_HOST) return deliver(ctx, proof_out, ZIP_MEM_HOST, out_d, total);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // small host inputs (coeffs, cols, q0) were consumed
     return check_timeout(ctx);
+}
+
+int32_t zip_verify(zip_ctx *ctx, const uint8_t *roots, const uint8_t *proof, zip_mem_kind proof_kind, size_t proof_len,
+                   const int64_t *coeffs, const uint32_t *cols, uint32_t n_cols, const uint64_t *q0_mont,
+                   const uint64_t *q1_mont, const uint64_t *eval_mont, const zip_field *field,
+                   zip_verify_report *report) {
+    if (!ctx || !roots || !proof || !report || !eval_mont || (n_cols && !cols)) return ZIP_ERR_NULL;
+    memset(report, 0, sizeof *report);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->rows_local != ctx->p.num_rows)
+        return fail(ctx, ZIP_ERR_INVALID_PARAM, "zip_verify needs an unsharded ctx");
+    HostField hf;
+    int32_t rc;
+    if ((rc = make_field(ctx, field, &hf))) return rc;
+    const uint32_t R = ctx->p.num_rows, C = ctx->p.row_len;
+    const bool single = R == 1;
+    if (!single && (!coeffs || !q0_mont)) return fail(ctx, ZIP_ERR_NULL, "coeffs / q0_mont is NULL");
+    if (C > 1 && !q1_mont) return fail(ctx, ZIP_ERR_NULL, "q1_mont is NULL");
+    if ((rc = check_cols(ctx, cols, n_cols))) return rc;
+    const size_t need = zip_proof_len(ctx, n_cols, hf.fl);
+    if (proof_len < need) {  // the reference runs out of stream: read_* fails (pcs_transcript.rs:125-160)
+        report->verdict = ZIP_VERIFY_MALFORMED;
+        return ZIP_OK;
+    }
+    Scratch pbuf(ctx), small(ctx);
+    const uint8_t *proof_d = proof;
+    if (proof_kind == ZIP_MEM_HOST) {
+        if ((rc = pbuf.get(need))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(pbuf.ptr, proof, need, hipMemcpyHostToDevice, ctx->stream));
+        proof_d = pbuf.as<uint8_t>();
+    }
+    // q_1 of a one-column matrix is empty in the reference (pcs/utils.rs:253-276): <row, q1> is then 0
+    SmallInputs si;
+    si.src[0] = coeffs;  si.bytes[0] = single ? 0 : (size_t)R * 8;
+    si.src[1] = q0_mont; si.bytes[1] = single ? 0 : (size_t)R * hf.fl * 8;
+    si.src[2] = cols;    si.bytes[2] = (size_t)n_cols * 4;
+    si.src[3] = q1_mont; si.bytes[3] = C > 1 ? (size_t)C * hf.fl * 8 : 0;
+    si.src[4] = roots;   si.bytes[4] = (size_t)R * 32;
+    unsigned char *sb;
+    if ((rc = stage_small(ctx, si, small, &sb))) return rc;
+    VerifyIn in{};
+    in.proof_d = proof_d;
+    in.coeffs_d = reinterpret_cast<const int64_t *>(sb + si.off[0]);
+    in.q0_d = reinterpret_cast<const uint64_t *>(sb + si.off[1]);
+    in.cols_d = reinterpret_cast<const uint32_t *>(sb + si.off[2]);
+    in.q1_d = reinterpret_cast<const uint64_t *>(sb + si.off[3]);
+    in.roots_d = sb + si.off[4];
+    in.n_cols = n_cols;
+    std::vector<uint32_t> flags, bad, malformed;
+    VerifyCounters cnt{};
+    switch (hf.fl) {
+        case 2: rc = run_verify_fl<2>(ctx, in, hf, flags, bad, malformed, &cnt); break;
+        case 3: rc = run_verify_fl<3>(ctx, in, hf, flags, bad, malformed, &cnt); break;
+        default: rc = run_verify_fl<4>(ctx, in, hf, flags, bad, malformed, &cnt); break;
+    }
+    if (rc) return rc;
+    for (uint32_t i = 0; i < n_cols; i++) {
+        report->bad_merkle_paths += bad[i];
+        report->malformed_paths += malformed[i];
+    }
+    // first failing check in the reference's order (verify_z.rs:60-163)
+    if (cnt.overflow) { report->verdict = ZIP_VERIFY_OVERFLOW; return ZIP_OK; }
+    for (uint32_t i = 0; i < n_cols; i++) {
+        if (flags[i] & 1u) { report->verdict = ZIP_VERIFY_PROXIMITY_TESTING; report->column = i; return ZIP_OK; }
+        if (malformed[i]) { report->verdict = ZIP_VERIFY_MALFORMED; report->column = i; return ZIP_OK; }
+        if (bad[i]) { report->verdict = ZIP_VERIFY_MERKLE; report->column = i; return ZIP_OK; }
+    }
+    if (cnt.noncanonical) { report->verdict = ZIP_VERIFY_MALFORMED; return ZIP_OK; }
+    if (C > 1 ? memcmp(cnt.dot, eval_mont, 8 * hf.fl) != 0 : [&] {
+            for (uint32_t i = 0; i < hf.fl; i++) if (eval_mont[i]) return true;
+            return false; }()) {
+        report->verdict = ZIP_VERIFY_EVAL_CONSISTENCY;
+        return ZIP_OK;
+    }
+    for (uint32_t i = 0; i < n_cols; i++)
+        if (flags[i] & 2u) { report->verdict = ZIP_VERIFY_PROXIMITY_Q0; report->column = i; return ZIP_OK; }
+    report->verdict = ZIP_VERIFY_ACCEPT;
+    return ZIP_OK;
+}
+
+int32_t zip_mle_eval(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_kind, const uint64_t *q0_mont,
+                     const uint64_t *q1_mont, const zip_field *field, uint64_t *value_out) {
+    if (!ctx || !value_out) return ZIP_ERR_NULL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->rows_local != ctx->p.num_rows)
+        return fail(ctx, ZIP_ERR_INVALID_PARAM, "zip_mle_eval needs an unsharded ctx");
+    HostField hf;
+    int32_t rc;
+    if ((rc = make_field(ctx, field, &hf))) return rc;
+    const uint32_t R = ctx->p.num_rows, C = ctx->p.row_len;
+    const bool single = R == 1;
+    if (!single && !q0_mont) return fail(ctx, ZIP_ERR_NULL, "q0_mont is NULL");
+    if (C > 1 && !q1_mont) return fail(ctx, ZIP_ERR_NULL, "q1_mont is NULL");
+    Scratch ev(ctx), row(ctx), small(ctx), res(ctx);
+    const int64_t *evals_d;
+    if ((rc = stage_evals(ctx, evals, evals_kind, (size_t)R * C, ev, &evals_d))) return rc;
+    if ((rc = row.get((size_t)C * hf.fl * 8))) return rc;
+    if ((rc = res.get(64))) return rc;
+    SmallInputs si;
+    si.src[1] = single ? hf.r : q0_mont;
+    si.bytes[1] = (size_t)R * hf.fl * 8;
+    si.src[3] = C > 1 ? (const void *)q1_mont : (const void *)hf.r;  // a one-column matrix evaluates to its entry
+    si.bytes[3] = (size_t)C * hf.fl * 8;
+    unsigned char *sb;
+    if ((rc = stage_small(ctx, si, small, &sb))) return rc;
+    CombineOut o{};
+    o.row_limbs = row.as<uint64_t>();
+    if ((rc = run_combine(ctx, evals_d, nullptr, reinterpret_cast<const uint64_t *>(sb + si.off[1]), &hf, false, true, o)))
+        return rc;
+    {
+        LaunchTimer t(ctx, "field_dot_kernel");
+        const uint64_t *q1d = reinterpret_cast<const uint64_t *>(sb + si.off[3]);
+        switch (hf.fl) {
+            case 2: hipLaunchKernelGGL(field_dot_kernel<2>, dim3(1), dim3(1024), 0, ctx->stream, o.row_limbs, q1d, C, res.as<uint64_t>(), to_dev<2>(hf)); break;
+            case 3: hipLaunchKernelGGL(field_dot_kernel<3>, dim3(1), dim3(1024), 0, ctx->stream, o.row_limbs, q1d, C, res.as<uint64_t>(), to_dev<3>(hf)); break;
+            default: hipLaunchKernelGGL(field_dot_kernel<4>, dim3(1), dim3(1024), 0, ctx->stream, o.row_limbs, q1d, C, res.as<uint64_t>(), to_dev<4>(hf)); break;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return deliver(ctx, value_out, ZIP_MEM_HOST, res.ptr, (size_t)hf.fl * 8);
+}
+
+int32_t zip_field_map_int256(zip_ctx *ctx, const uint64_t *values, uint32_t n, const zip_field *field, uint64_t *out) {
+    if (!ctx || !values || !out) return ZIP_ERR_NULL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HostField hf, hq;
+    int32_t rc;
+    if ((rc = make_field(ctx, field, &hf))) return rc;
+    const bool quirk = make_quirk_field(hf, &hq);
+    Scratch in(ctx), res(ctx);
+    if ((rc = in.get((size_t)n * 32 + 16))) return rc;
+    if ((rc = res.get((size_t)n * hf.fl * 8 + 16))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(in.ptr, values, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream));
+    const dim3 grid((n + 255) / 256), block(256);
+    switch (hf.fl) {
+        case 2: hipLaunchKernelGGL(field_map_int256_kernel<2>, grid, block, 0, ctx->stream, in.as<uint64_t>(), n, res.as<uint64_t>(), to_dev<2>(hf), to_dev<2>(hf), 0u); break;
+        case 3: hipLaunchKernelGGL(field_map_int256_kernel<3>, grid, block, 0, ctx->stream, in.as<uint64_t>(), n, res.as<uint64_t>(), to_dev<3>(hf), to_dev<3>(hf), 0u); break;
+        default: hipLaunchKernelGGL(field_map_int256_kernel<4>, grid, block, 0, ctx->stream, in.as<uint64_t>(), n, res.as<uint64_t>(), to_dev<4>(hf), quirk ? to_dev<4>(hq) : to_dev<4>(hf), quirk ? 1u : 0u); break;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return deliver(ctx, out, ZIP_MEM_HOST, res.ptr, (size_t)n * hf.fl * 8);
 }
 
 int32_t zip_sum_partials(zip_ctx *ctx, const uint64_t *uparts, const uint64_t *fparts, uint32_t n_parts,

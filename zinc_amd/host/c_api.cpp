@@ -22,7 +22,9 @@ int32_t guarded(F &&f) {
         return ZINC_OK;
     } catch (const ZipError &e) {
         g_err = e.what();
-        return e.kind == ZipError::InvalidPcsParam ? ZINC_ERR_INVALID_PARAM : ZINC_ERR_DEVICE;
+        return e.kind == ZipError::InvalidPcsParam ? ZINC_ERR_INVALID_PARAM
+               : (e.kind == ZipError::InvalidPcsOpen || e.kind == ZipError::Transcript) ? ZINC_ERR_INVALID_OPEN
+                                                                                        : ZINC_ERR_DEVICE;
     } catch (const std::logic_error &e) {  // where the reference panics
         g_err = e.what();
         return ZINC_ERR_PANIC;
@@ -178,5 +180,67 @@ int32_t zinc_zip_open(const zinc_zip_params *pp, const int64_t *evals, size_t n_
         MultilinearZip::open(pp->pp, evals, n_evals, poly_num_vars, data->d, pt.data(), point_len, f, transcript->t);
     });
 }
+
+zinc_pcs_transcript *zinc_pcs_transcript_from_proof(const uint8_t *proof, size_t len) {
+    auto *t = new zinc_pcs_transcript();
+    t->t = PcsTranscript::from_proof(proof, len);
+    return t;
+}
+size_t zinc_pcs_transcript_position(const zinc_pcs_transcript *t) { return t->t.read_pos; }
+
+int32_t zinc_zip_verify(const zinc_zip_params *vp, const uint8_t *roots, const uint64_t *point, size_t point_len,
+                        const uint64_t *eval, const uint64_t *modulus, uint32_t limbs, zinc_pcs_transcript *transcript) {
+    if (!vp || !roots || !eval || !transcript) return ZINC_ERR_NULL;
+    return guarded([&] {
+        const FieldConfig f = FieldConfig::make(modulus, limbs);
+        std::vector<Limbs> pt(point_len);
+        for (size_t i = 0; i < point_len; i++) pt[i] = load(point + i * limbs, limbs);
+        MultilinearZipCommitment comm;
+        comm.roots.resize(vp->pp.num_rows);
+        std::memcpy(comm.roots.data(), roots, (size_t)vp->pp.num_rows * 32);
+        MultilinearZip::verify(vp->pp, comm, pt.data(), point_len, load(eval, limbs), transcript->t, f);
+    });
+}
+
+int32_t zinc_zip_evaluate(const zinc_zip_params *pp, const int64_t *evals, size_t n_evals, const uint64_t *point,
+                          size_t point_len, const uint64_t *modulus, uint32_t limbs, uint64_t *out) {
+    if (!pp || !evals || !out) return ZINC_ERR_NULL;
+    return guarded([&] {
+        const FieldConfig f = FieldConfig::make(modulus, limbs);
+        std::vector<Limbs> pt(point_len);
+        for (size_t i = 0; i < point_len; i++) pt[i] = load(point + i * limbs, limbs);
+        const Limbs v = MultilinearZip::evaluate(pp->pp, evals, n_evals, pt.data(), point_len, f);
+        for (uint32_t i = 0; i < limbs; i++) out[i] = v[i];
+    });
+}
+
+struct zinc_zip_proof {
+    zinc::zip::ZipProof p;
+    uint32_t limbs;
+};
+int32_t zinc_commit_z_mle_and_prove_evaluation(const int64_t *z_evals, size_t m, const uint64_t *r_y, size_t r_y_len,
+                                               zinc_transcript *transcript, const uint64_t *modulus, uint32_t limbs,
+                                               int32_t device, zinc_zip_proof **out) {
+    if (!z_evals || !transcript || !out) return ZINC_ERR_NULL;
+    *out = nullptr;
+    return guarded([&] {
+        const FieldConfig f = FieldConfig::make(modulus, limbs);
+        std::vector<Limbs> pt(r_y_len);
+        for (size_t i = 0; i < r_y_len; i++) pt[i] = load(r_y + i * limbs, limbs);
+        auto *res = new zinc_zip_proof{
+            zinc::zip::commit_z_mle_and_prove_evaluation(LinearCodeSpec{}, z_evals, m, pt.data(), r_y_len, transcript->t, f, device),
+            limbs};
+        *out = res;
+    });
+}
+size_t zinc_zip_proof_len(const zinc_zip_proof *p) { return p->p.pcs_proof.size(); }
+size_t zinc_zip_proof_num_roots(const zinc_zip_proof *p) { return p->p.z_comm.roots.size(); }
+void zinc_zip_proof_read(const zinc_zip_proof *p, uint8_t *roots_out, uint64_t *v_out, uint8_t *pcs_proof_out) {
+    if (roots_out) std::memcpy(roots_out, p->p.z_comm.roots.data(), p->p.z_comm.roots.size() * 32);
+    if (v_out)
+        for (uint32_t i = 0; i < p->limbs; i++) v_out[i] = p->p.v[i];
+    if (pcs_proof_out) std::memcpy(pcs_proof_out, p->p.pcs_proof.data(), p->p.pcs_proof.size());
+}
+void zinc_zip_proof_free(zinc_zip_proof *p) { delete p; }
 
 }  // extern "C"

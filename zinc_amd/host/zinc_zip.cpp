@@ -623,5 +623,105 @@ void MultilinearZip::open(const MultilinearZipParams &pp, const int64_t *evals, 
     }
 }
 
+// point_to_tensor (pcs/utils.rs:252-276): q_0 over the last log2(num_rows) coordinates, q_1 over the rest;
+// an empty half gives an EMPTY vector (MLE::zero()).
+static void point_to_tensor(const FieldConfig &field, uint32_t num_rows, const Limbs *point, size_t point_len,
+                            std::vector<uint64_t> &q0, std::vector<uint64_t> &q1) {
+    const uint32_t lr = ilog2(num_rows);
+    const size_t lc = point_len - lr;
+    auto flat = [&](const std::vector<Limbs> &eq, std::vector<uint64_t> &out) {
+        out.resize(eq.size() * field.limbs);
+        for (size_t i = 0; i < eq.size(); i++)
+            for (uint32_t k = 0; k < field.limbs; k++) out[i * field.limbs + k] = eq[i][k];
+    };
+    q0.clear();
+    q1.clear();
+    if (lr) flat(build_eq_x_r(field, point + lc, lr), q0);
+    if (lc) flat(build_eq_x_r(field, point, (uint32_t)lc), q1);
+}
+
+void MultilinearZip::verify(const MultilinearZipParams &vp, const MultilinearZipCommitment &comm, const Limbs *point,
+                            size_t point_len, const Limbs &eval, PcsTranscript &transcript, const FieldConfig &field) {
+    validate_input("verify", vp.num_vars, vp.num_vars, &point_len);
+    const uint32_t row_len = vp.linear_code.row_len, num_rows = vp.num_rows, cw = vp.linear_code.codeword_len();
+    if (comm.roots.size() != num_rows) throw ZipError(ZipError::InvalidPcsOpen, "commitment has the wrong number of roots");
+    zip_ctx *ctx = vp.ctx.get();
+    // the challenges in the order verify_testing draws them (verify_z.rs:69-90); reads never absorb
+    std::vector<int64_t> coeffs;
+    if (num_rows > 1) {
+        if (vp.linear_code.num_proximity_testing != 1)
+            throw ZipError(ZipError::InvalidPcsParam, "only one proximity test is supported on the device path");
+        coeffs = transcript.fs_transcript.get_integer_challenges_i64(num_rows);
+    }
+    std::vector<uint32_t> cols(vp.linear_code.num_column_opening);
+    for (auto &c : cols) c = (uint32_t)transcript.squeeze_challenge_idx(field, cw);
+    std::vector<uint64_t> q0, q1;
+    point_to_tensor(field, num_rows, point, point_len, q0, q1);
+    const zip_field zf = field.to_abi();
+    const size_t len = zip_proof_len(ctx, (uint32_t)cols.size(), field.limbs);
+    const size_t avail = transcript.stream.size() - transcript.read_pos;
+    zip_verify_report rep{};
+    check(ctx,
+          zip_verify(ctx, comm.roots.empty() ? nullptr : comm.roots[0].data(), transcript.stream.data() + transcript.read_pos,
+                     ZIP_MEM_HOST, avail, coeffs.empty() ? nullptr : coeffs.data(), cols.data(), (uint32_t)cols.size(),
+                     q0.empty() ? nullptr : q0.data(), q1.empty() ? nullptr : q1.data(), eval.data(), &zf, &rep),
+          "zip_verify");
+    switch (rep.verdict) {
+        case ZIP_VERIFY_ACCEPT: break;
+        case ZIP_VERIFY_PROXIMITY_TESTING:
+        case ZIP_VERIFY_PROXIMITY_Q0: throw ZipError(ZipError::InvalidPcsOpen, "Proximity failure");
+        case ZIP_VERIFY_EVAL_CONSISTENCY: throw ZipError(ZipError::InvalidPcsOpen, "Evaluation consistency failure");
+        case ZIP_VERIFY_MERKLE: throw ZipError(ZipError::InvalidPcsOpen, "Merkle proof verification failed");
+        case ZIP_VERIFY_OVERFLOW: throw std::logic_error("attempt to add with overflow (encode_wide of the combined row)");
+        default: throw ZipError(ZipError::Transcript, "Failed to read the proof stream");
+    }
+    // read_field_elements absorbed every element of the evaluation row (pcs_transcript.rs:138-160)
+    const uint8_t *row_be = transcript.stream.data() + transcript.read_pos + len - (size_t)row_len * field.limbs * 8;
+    for (uint32_t c = 0; c < row_len; c++) {
+        Limbs v{};
+        const uint8_t *b = row_be + (size_t)c * field.limbs * 8;
+        for (uint32_t i = 0; i < field.limbs; i++) {
+            uint64_t w = 0;
+            for (int k = 0; k < 8; k++) w = (w << 8) | b[8 * (field.limbs - 1 - i) + k];
+            v[i] = w;
+        }
+        transcript.fs_transcript.absorb_random_field(field, v);
+    }
+    transcript.read_pos += len;
+}
+
+Limbs MultilinearZip::evaluate(const MultilinearZipParams &pp, const int64_t *evals, size_t n_evals, const Limbs *point,
+                               size_t point_len, const FieldConfig &field) {
+    if (point_len != pp.num_vars)
+        throw ZipError(ZipError::InvalidPcsParam, "IncorrectLength: the point does not have num_vars coordinates");
+    if (n_evals != (size_t)pp.linear_code.row_len * pp.num_rows) throw std::logic_error("evaluations do not fill the matrix");
+    std::vector<uint64_t> q0, q1;
+    point_to_tensor(field, pp.num_rows, point, point_len, q0, q1);
+    const zip_field zf = field.to_abi();
+    Limbs v{};
+    check(pp.ctx.get(),
+          zip_mle_eval(pp.ctx.get(), evals, ZIP_MEM_HOST, q0.empty() ? nullptr : q0.data(), q1.empty() ? nullptr : q1.data(),
+                       &zf, v.data()),
+          "zip_mle_eval");
+    return v;
+}
+
 }  // namespace zip
+
+zip::ZipProof zip::commit_z_mle_and_prove_evaluation(const LinearCodeSpec &lc_spec, const int64_t *z_evals, size_t m,
+                                                     const Limbs *r_y, size_t r_y_len, KeccakTranscript &transcript,
+                                                     const FieldConfig &config, int device) {
+    KeccakSeedSource seeds(transcript);
+    const RaaCode linear_code = RaaCode::make(lc_spec, m, seeds);               // prover.rs:313
+    const MultilinearZipParams param = MultilinearZip::setup(m, linear_code, device);  // :314
+    auto committed = MultilinearZip::commit(param, z_evals, m, param.num_vars);  // :315
+    PcsTranscript pcs_transcript;                                                // :316 (fresh)
+    ZipProof out;
+    out.v = MultilinearZip::evaluate(param, z_evals, m, r_y, r_y_len, config);    // :317-319
+    MultilinearZip::open(param, z_evals, m, param.num_vars, committed.first, r_y, r_y_len, config, pcs_transcript);  // :320
+    out.z_comm = std::move(committed.second);
+    out.pcs_proof = pcs_transcript.into_proof();
+    return out;
+}
+
 }  // namespace zinc

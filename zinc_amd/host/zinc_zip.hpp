@@ -143,6 +143,13 @@ struct RaaCode {
 struct PcsTranscript {
     KeccakTranscript fs_transcript;
     std::vector<uint8_t> stream;
+    size_t read_pos = 0;  // Cursor position of the reading side (PcsTranscript::from_proof, :28-35)
+
+    static PcsTranscript from_proof(const uint8_t *proof, size_t len) {
+        PcsTranscript t;
+        t.stream.assign(proof, proof + len);
+        return t;
+    }
 
     void write_field_elements(const FieldConfig &f, const Limbs *elems, size_t n);  // :76-113
     void append(const uint8_t *bytes, size_t n) { stream.insert(stream.end(), bytes, bytes + n); }
@@ -182,7 +189,28 @@ struct MultilinearZip {
     static void open(const MultilinearZipParams &pp, const int64_t *evals, size_t n_evals, uint32_t poly_num_vars,
                      const MultilinearZipData &commit_data, const Limbs *point, size_t point_len,
                      const FieldConfig &field, PcsTranscript &transcript);
+    // verify_z.rs:19-38.  Throws ZipError{InvalidPcsOpen} with the reference's message when a check
+    // fails ("Proximity failure", "Evaluation consistency failure"), std::logic_error where the
+    // reference panics (encode_wide overflow).  Merkle paths are checked (zip_hip.h, zip_verify).
+    static void verify(const MultilinearZipParams &vp, const MultilinearZipCommitment &comm, const Limbs *point,
+                       size_t point_len, const Limbs &eval, PcsTranscript &transcript, const FieldConfig &field);
+    // z_mle.map_to_field(config).evaluate(r_y, config) (zinc/prover.rs:317-319; poly_f/mle/dense.rs:35-41):
+    // nullopt-like failure (wrong point length) throws ZipError{InvalidPcsParam}.
+    static Limbs evaluate(const MultilinearZipParams &pp, const int64_t *evals, size_t n_evals, const Limbs *point,
+                          size_t point_len, const FieldConfig &field);
 };
+
+// ZipProof (src/zinc/structs.rs:26-30) and the PCS step of the prover,
+// ZincProver::commit_z_mle_and_prove_evaluation (src/zinc/prover.rs:305-327): code from the main
+// transcript, setup, commit, v = z_mle(r_y), open on a FRESH PcsTranscript.
+struct ZipProof {
+    MultilinearZipCommitment z_comm;
+    Limbs v{};
+    std::vector<uint8_t> pcs_proof;
+};
+ZipProof commit_z_mle_and_prove_evaluation(const LinearCodeSpec &lc_spec, const int64_t *z_evals, size_t m,
+                                           const Limbs *r_y, size_t r_y_len, KeccakTranscript &transcript,
+                                           const FieldConfig &config, int device = 0);
 
 }  // namespace zip
 }  // namespace zinc

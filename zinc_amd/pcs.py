@@ -10,7 +10,7 @@ from . import cabi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libzinc_zip.so")
-OK, ERR_INVALID_PARAM, ERR_PANIC, ERR_DEVICE, ERR_NULL = 0, -1, -2, -3, -4
+OK, ERR_INVALID_PARAM, ERR_PANIC, ERR_DEVICE, ERR_NULL, ERR_INVALID_OPEN = 0, -1, -2, -3, -4, -5
 
 EXPORTED_SYMBOLS = (
     "zinc_last_error", "zinc_transcript_new", "zinc_transcript_free", "zinc_transcript_absorb",
@@ -19,12 +19,18 @@ EXPORTED_SYMBOLS = (
     "zinc_shuffle_seeded_perm", "zinc_raa_code_new", "zinc_zip_setup", "zinc_zip_params_free",
     "zinc_zip_params_geometry", "zinc_zip_commit", "zinc_zip_data_free", "zinc_pcs_transcript_new",
     "zinc_pcs_transcript_free", "zinc_pcs_transcript_len", "zinc_pcs_transcript_copy",
-    "zinc_pcs_transcript_probe", "zinc_zip_open",
+    "zinc_pcs_transcript_probe", "zinc_zip_open", "zinc_pcs_transcript_from_proof", "zinc_pcs_transcript_position",
+    "zinc_zip_verify", "zinc_zip_evaluate", "zinc_commit_z_mle_and_prove_evaluation", "zinc_zip_proof_len",
+    "zinc_zip_proof_num_roots", "zinc_zip_proof_read", "zinc_zip_proof_free",
 )
 
 
 class InvalidPcsParam(ValueError):
     """zip::Error::InvalidPcsParam"""
+
+
+class InvalidPcsOpen(ValueError):
+    """zip::Error::InvalidPcsOpen / a transcript read error: the proof is rejected."""
 
 
 class ReferencePanic(AssertionError):
@@ -79,6 +85,21 @@ def lib():
         L.zinc_pcs_transcript_probe.argtypes = [vp]
         L.zinc_pcs_transcript_probe.restype = C.c_uint64
         L.zinc_zip_open.argtypes = [vp, vp, C.c_size_t, C.c_uint32, vp, vp, C.c_size_t, vp, C.c_uint32, vp]
+        L.zinc_pcs_transcript_from_proof.argtypes = [vp, C.c_size_t]
+        L.zinc_pcs_transcript_from_proof.restype = vp
+        L.zinc_pcs_transcript_position.argtypes = [vp]
+        L.zinc_pcs_transcript_position.restype = C.c_size_t
+        L.zinc_zip_verify.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.c_uint32, vp]
+        L.zinc_zip_evaluate.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_uint32, vp]
+        L.zinc_commit_z_mle_and_prove_evaluation.argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp, vp, C.c_uint32,
+                                                             C.c_int32, C.POINTER(vp)]
+        L.zinc_zip_proof_len.argtypes = [vp]
+        L.zinc_zip_proof_len.restype = C.c_size_t
+        L.zinc_zip_proof_num_roots.argtypes = [vp]
+        L.zinc_zip_proof_num_roots.restype = C.c_size_t
+        L.zinc_zip_proof_read.argtypes = [vp, vp, vp, vp]
+        L.zinc_zip_proof_read.restype = None
+        L.zinc_zip_proof_free.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -89,6 +110,8 @@ def _check(rc):
     msg = lib().zinc_last_error().decode()
     if rc == ERR_INVALID_PARAM:
         raise InvalidPcsParam(msg)
+    if rc == ERR_INVALID_OPEN:
+        raise InvalidPcsOpen(msg)
     if rc == ERR_PANIC:
         raise ReferencePanic(msg)
     raise DeviceError(msg)
@@ -179,8 +202,16 @@ class RaaCode:
 
 
 class PcsTranscript:
-    def __init__(self):
-        self._h = lib().zinc_pcs_transcript_new()
+    def __init__(self, _handle=None):
+        self._h = _handle if _handle is not None else lib().zinc_pcs_transcript_new()
+
+    @classmethod
+    def from_proof(cls, proof) -> "PcsTranscript":
+        p = np.ascontiguousarray(proof, dtype=np.uint8)
+        return cls(lib().zinc_pcs_transcript_from_proof(p.ctypes.data, p.size))
+
+    def position(self) -> int:
+        return lib().zinc_pcs_transcript_position(self._h)
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -244,3 +275,42 @@ class MultilinearZip:
         pt = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, field.limbs) if np.size(point) else np.zeros((0, field.limbs), np.uint64)
         _check(lib().zinc_zip_open(pp._h, ev.ctypes.data, ev.size, nv, commit_data._h, pt.ctypes.data, pt.shape[0],
                                    field._m.ctypes.data, field.limbs, transcript._h))
+
+    @staticmethod
+    def verify(vp: MultilinearZipParams, roots, point: np.ndarray, eval_mont, field: FieldConfig,
+               transcript: PcsTranscript):
+        """MultilinearZip::verify: returns None when the proof is accepted, raises InvalidPcsOpen otherwise."""
+        r = np.ascontiguousarray(roots, dtype=np.uint8)
+        pt = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, field.limbs) if np.size(point) else np.zeros((0, field.limbs), np.uint64)
+        ev = np.ascontiguousarray(eval_mont, dtype=np.uint64)
+        _check(lib().zinc_zip_verify(vp._h, r.ctypes.data, pt.ctypes.data, pt.shape[0], ev.ctypes.data,
+                                     field._m.ctypes.data, field.limbs, transcript._h))
+
+    @staticmethod
+    def evaluate(pp: MultilinearZipParams, evaluations, point: np.ndarray, field: FieldConfig) -> np.ndarray:
+        """z_mle.map_to_field(config).evaluate(point) (zinc/prover.rs:317-319)."""
+        ev = np.ascontiguousarray(evaluations, dtype=np.int64)
+        pt = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, field.limbs) if np.size(point) else np.zeros((0, field.limbs), np.uint64)
+        out = np.zeros(field.limbs, np.uint64)
+        _check(lib().zinc_zip_evaluate(pp._h, ev.ctypes.data, ev.size, pt.ctypes.data, pt.shape[0], field._m.ctypes.data,
+                                       field.limbs, out.ctypes.data))
+        return out
+
+
+def commit_z_mle_and_prove_evaluation(z_evals, r_y: np.ndarray, transcript: KeccakTranscript, field: FieldConfig,
+                                      device: int = 0):
+    """ZincProver::commit_z_mle_and_prove_evaluation (src/zinc/prover.rs:305-327) -> (roots, v, pcs_proof)."""
+    ev = np.ascontiguousarray(z_evals, dtype=np.int64)
+    pt = np.ascontiguousarray(r_y, dtype=np.uint64).reshape(-1, field.limbs) if np.size(r_y) else np.zeros((0, field.limbs), np.uint64)
+    h = C.c_void_p()
+    _check(lib().zinc_commit_z_mle_and_prove_evaluation(ev.ctypes.data, ev.size, pt.ctypes.data, pt.shape[0],
+                                                        transcript._h, field._m.ctypes.data, field.limbs, device,
+                                                        C.byref(h)))
+    try:
+        roots = np.zeros((lib().zinc_zip_proof_num_roots(h), 32), np.uint8)
+        v = np.zeros(field.limbs, np.uint64)
+        proof = np.zeros(lib().zinc_zip_proof_len(h), np.uint8)
+        lib().zinc_zip_proof_read(h, roots.ctypes.data, v.ctypes.data, proof.ctypes.data)
+    finally:
+        lib().zinc_zip_proof_free(h)
+    return roots, v, proof
