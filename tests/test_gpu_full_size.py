@@ -75,6 +75,20 @@ def test_commit_open_2pow24(env):
     bad[proof.size // 2] ^= 1
     assert z.verify(f, roots, point, ev, bad, check_merkle=True) != 0
 
+    # the device verifier (zip_verify) agrees with the oracle's on the full-size stream, and the witness
+    # MLE evaluation (prover.rs:317-319) equals the oracle's
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    q1 = orc.build_eq_x_r(f, point[: nv - lr])
+    ev_limbs = np.array(orc.int_to_limbs(ev, 4), dtype=np.uint64)
+    d_proof = torch.from_numpy(proof).cuda()
+    rep = ctx.verify(roots, d_proof, coeffs, cols, q0, q1, ev_limbs, zf)
+    assert rep == {"verdict": cabi.VERIFY_ACCEPT, "column": 0, "bad_merkle_paths": 0, "malformed_paths": 0}
+    d_proof[proof.size // 2] ^= 1
+    rep = ctx.verify(roots, d_proof, coeffs, cols, q0, q1, ev_limbs, zf)
+    assert rep["verdict"] != cabi.VERIFY_ACCEPT
+    assert orc.limbs_to_int(ctx.mle_eval(d_evals, q0, q1, zf)) == ev
+    del d_proof
+
     # linearity of the proximity row: unit coefficients select a witness row (combine_rows definition)
     unit = np.zeros(z.num_rows, dtype=np.int64)
     unit[777] = 1

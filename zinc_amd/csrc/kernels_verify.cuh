@@ -92,17 +92,23 @@ __global__ void __launch_bounds__(1024) encode_row_kernel(const uint64_t *in, ui
         }
         tot[tid] = sum;
         __syncthreads();
-        if (tid == 0) {  // exclusive scan of the T chunk totals; T <= 1024 additions
-            El run;
-            enc_zero<L, FIELD>(run);
-            for (uint32_t t = 0; t < T; t++) {
-                const El cur = tot[t];
-                tot[t] = run;
-                enc_add<L, FIELD>(run, cur, f);
+        // inclusive scan of the T chunk totals in place (Hillis-Steele, log2 T rounds) ...
+        for (uint32_t off = 1; off < T; off <<= 1) {
+            El x;
+            enc_zero<L, FIELD>(x);
+            if (tid >= off) x = tot[tid - off];
+            __syncthreads();
+            if (tid >= off) {
+                El y = tot[tid];
+                enc_add<L, FIELD>(y, x, f);
+                tot[tid] = y;
             }
+            __syncthreads();
         }
-        __syncthreads();
-        El run = tot[tid];
+        // ... of which thread t needs the exclusive value: the sum of the chunks before its own
+        El run;
+        enc_zero<L, FIELD>(run);
+        if (tid) run = tot[tid - 1];
         uint64_t *dst = pass == 0 ? tmp : out;
         // pass 1 reads tmp while pass 0 of no other thread writes it any more; pass 0 writes tmp
         // only after every thread has finished READING `in`: no hazard.  Pass 1 writes `out`.
