@@ -146,6 +146,19 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
                  const uint32_t *cols, uint32_t n_cols, const uint64_t *q0_mont, const zip_field *field,
                  uint8_t *proof_out, zip_mem_kind out_kind);
 
+/* ---- streaming proof writer -------------------------------
+ * zip_open with the stream delivered to `sink` in order, piece by piece (u', then groups of opened
+ * columns, then the evaluation row), instead of into one contiguous buffer: the 1.74 GiB proof of a
+ * 2^24 witness never needs a single host allocation, and the PCIe copy of one group overlaps the
+ * gather of the next.  `bytes` points into pinned memory owned by the library and is valid only
+ * during the call; a non-zero return from the sink aborts (ZIP_ERR_INVALID_PARAM).
+ * chunk_bytes: target size of a column group (0 = 64 MiB).  The concatenation of all pieces is
+ * byte-identical to what zip_open writes. */
+typedef int32_t (*zip_proof_sink)(void *user, const uint8_t *bytes, size_t len);
+int32_t zip_open_stream(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kind, const int64_t *coeffs,
+                        const uint32_t *cols, uint32_t n_cols, const uint64_t *q0_mont, const zip_field *field,
+                        zip_proof_sink sink, void *user, size_t chunk_bytes);
+
 /* ---- verifier side ---------------------------------------------
  * MultilinearZip::verify (src/zip/pcs/verify_z.rs:19-188) on the device.  The caller (the Rust
  * shim / zinc_amd/host) keeps the Fiat-Shamir work: it squeezes `coeffs` (num_rows, only when

@@ -273,3 +273,36 @@ def test_profiling_hooks_report_kernels(cabi):
     times = ctx.profile_read()
     assert "raa_commit_kernel" in times and times["raa_commit_kernel"][0] == 1
     assert times["raa_commit_kernel"][1] > 0
+
+
+@pytest.mark.parametrize("num_vars,chunk", [(0, 0), (3, 1), (8, 4096), (12, 1 << 16), (14, 0)])
+def test_open_stream_pieces_concatenate_to_the_proof(cabi, num_vars, chunk):
+    """zip_open_stream: u', column groups, evaluation row, in order, byte-identical
+    to the contiguous proof of zip_open -- whatever the group size."""
+    z = orc.Zip(num_vars)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    evals = _witness(num_vars, seed=9)
+    point = orc.point_to_field(f, np.arange(num_vars, dtype=np.int64) - 3) if num_vars else np.zeros((0, 4), dtype=np.uint64)
+    rows_o, layers_o, _ = z.commit(evals)
+    proof_o, cols, coeffs = z.open(f, evals, rows_o, layers_o, point, orc.new_transcript())
+    lr = z.num_rows.bit_length() - 1
+    q0 = orc.build_eq_x_r(f, point[num_vars - lr:]) if lr else None
+    cf = coeffs if z.num_rows > 1 else None
+    ctx = _ctx(cabi, z)
+    com, _ = ctx.commit(evals)
+    pieces = []
+    com.open_stream(evals, cf, cols, q0, cabi.make_field(BENCH_MODULUS, 4), lambda mv: pieces.append(bytes(mv)) and None,
+                    chunk_bytes=chunk)
+    assert b"".join(pieces) == proof_o.tobytes()
+    per_col = z.num_rows * (32 + 8 + 32 * z.depth)
+    assert all(len(p) % per_col == 0 for p in pieces[(1 if z.num_rows > 1 else 0):-1])  # whole columns per piece
+    if chunk == 1:
+        assert len(pieces) == (1 if z.num_rows > 1 else 0) + len(cols) + 1
+    # a sink that refuses the stream aborts the call
+    seen = []
+    with pytest.raises(cabi.ZipError):
+        com.open_stream(evals, cf, cols, q0, cabi.make_field(BENCH_MODULUS, 4),
+                        lambda mv: seen.append(len(mv)) or len(seen) >= 2, chunk_bytes=chunk)
+    assert len(seen) == 2
+    # the handle is still usable afterwards
+    assert com.open(evals, cf, cols, q0, cabi.make_field(BENCH_MODULUS, 4)).tobytes() == proof_o.tobytes()

@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "zip_commitment_device_ptrs", "zip_commit_download", "zip_commitment_upload", "zip_open_testing",
     "zip_open_columns", "zip_open_eval", "zip_proof_len", "zip_open", "zip_sum_partials", "zip_merkle_trees",
     "zip_ctx_set_profiling", "zip_ctx_profile_read", "zip_verify", "zip_mle_eval", "zip_field_map_int256",
+    "zip_open_stream",
 )
 
 
@@ -59,6 +60,9 @@ class VerifyReport(C.Structure):
 
 VERIFY_ACCEPT, VERIFY_PROXIMITY_TESTING, VERIFY_EVAL_CONSISTENCY, VERIFY_PROXIMITY_Q0 = 0, 1, 2, 3
 VERIFY_MERKLE, VERIFY_MALFORMED, VERIFY_OVERFLOW = 4, 5, 6
+
+
+PROOF_SINK = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
 class KernelTime(C.Structure):
@@ -103,6 +107,8 @@ def lib():
                              C.POINTER(ZipField), C.POINTER(VerifyReport)]
     L.zip_mle_eval.argtypes = [vp, i64p, C.c_int, u64p, u64p, C.POINTER(ZipField), u64p]
     L.zip_field_map_int256.argtypes = [vp, u64p, C.c_uint32, C.POINTER(ZipField), u64p]
+    L.zip_open_stream.argtypes = [vp, i64p, C.c_int, i64p, u32p, C.c_uint32, u64p, C.POINTER(ZipField), PROOF_SINK,
+                                  vp, C.c_size_t]
     L.zip_commitment_free.argtypes = [vp]
     L.zip_commitment_free.restype = None
     L.zip_commitment_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
@@ -121,7 +127,7 @@ def lib():
     for fn in ("zip_ctx_create", "zip_ctx_synchronize", "zip_commit", "zip_commitment_device_ptrs",
                "zip_commit_download", "zip_commitment_upload", "zip_open_testing", "zip_open_columns",
                "zip_open_eval", "zip_open", "zip_sum_partials", "zip_merkle_trees", "zip_ctx_set_profiling",
-               "zip_ctx_profile_read", "zip_verify", "zip_mle_eval", "zip_field_map_int256"):
+               "zip_ctx_profile_read", "zip_verify", "zip_mle_eval", "zip_field_map_int256", "zip_open_stream"):
         getattr(L, fn).restype = C.c_int32
     _lib = L
     return L
@@ -366,6 +372,25 @@ class Commitment:
         optr, okind = _ptr(res)
         c._check(lib().zip_open_columns(self._h, cols.ctypes.data, cols.size, optr, okind), "zip_open_columns")
         return res
+
+    def open_stream(self, evals, coeffs, cols, q0_mont, field: ZipField, sink, chunk_bytes=0):
+        """zip_open_stream: sink(memoryview) is called for each piece of the proof, in stream order;
+        return a truthy value from it to abort."""
+        c = self.ctx
+        ptr, kind = _ptr(evals)
+        cols = np.ascontiguousarray(cols, dtype=np.uint32)
+        coeffs_c = np.ascontiguousarray(coeffs, dtype=np.int64) if coeffs is not None else None
+        q0 = np.ascontiguousarray(q0_mont, dtype=np.uint64) if q0_mont is not None else None
+
+        def _sink(_user, p, n):
+            piece = (C.c_uint8 * n).from_address(p) if n else b""
+            return 1 if sink(memoryview(piece)) else 0
+
+        cb = PROOF_SINK(_sink)
+        rc = lib().zip_open_stream(self._h, ptr, kind, coeffs_c.ctypes.data if coeffs_c is not None else None,
+                                   cols.ctypes.data, cols.size, q0.ctypes.data if q0 is not None else None,
+                                   C.byref(field), cb, None, chunk_bytes)
+        c._check(rc, "zip_open_stream")
 
     def open(self, evals, coeffs, cols, q0_mont, field: ZipField, out=None):
         """Whole proof stream of MultilinearZip::open (the field elements still need absorbing)."""

@@ -4,6 +4,7 @@
 // validation mirroring the reference's error behaviour, kernel dispatch and the
 // HIP-event measurement hooks used by bench.py.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include <cstdarg>
 #include <cstdio>
@@ -61,6 +62,9 @@ struct zip_ctx {
     // truly asynchronous H2D copy instead of several pageable (blocking, staged) ones
     unsigned char *pinned_base = nullptr, *stage_h = nullptr, *stage_big = nullptr;
     size_t stage_cap = 0, stage_big_cap = 0;
+    // zip_open_stream: two pinned bounce buffers the proof leaves the device through
+    unsigned char *bounce[2] = {nullptr, nullptr};
+    size_t bounce_cap = 0;
     std::string last_error;
     // caching allocator: exact-size free lists
     std::multimap<size_t, void *> free_blocks;
@@ -903,6 +907,8 @@ void zip_ctx_destroy(zip_ctx *ctx) {
     if (ctx->s_aux) (void)hipStreamDestroy(ctx->s_aux);
     if (ctx->stage_big) (void)hipHostFree(ctx->stage_big);
     if (ctx->pinned_base) (void)hipHostFree(ctx->pinned_base);
+    for (auto *b : ctx->bounce)
+        if (b) (void)hipHostFree(b);
     if (ctx->perm1_d) (void)hipFree(ctx->perm1_d);
     if (ctx->perm2_d) (void)hipFree(ctx->perm2_d);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1423,6 +1429,124 @@ int32_t zip_field_map_int256(zip_ctx *ctx, const uint64_t *values, uint32_t n, c
     }
     HIP_TRY(ctx, hipGetLastError());
     return deliver(ctx, out, ZIP_MEM_HOST, res.ptr, (size_t)n * hf.fl * 8);
+}
+
+int32_t zip_open_stream(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kind, const int64_t *coeffs,
+                        const uint32_t *cols, uint32_t n_cols, const uint64_t *q0_mont, const zip_field *field,
+                        zip_proof_sink sink, void *user, size_t chunk_bytes) {
+    if (!c || !sink || (n_cols && !cols)) return ZIP_ERR_NULL;
+    zip_ctx *ctx = c->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->rows_local != ctx->p.num_rows)
+        return fail(ctx, ZIP_ERR_INVALID_PARAM, "zip_open_stream needs an unsharded ctx");
+    if (!c->layers) return fail(ctx, ZIP_ERR_INVALID_PARAM, "commitment has no Merkle trees (commit_no_merkle)");
+    HostField hf;
+    int32_t rc;
+    if ((rc = make_field(ctx, field, &hf))) return rc;
+    const bool single = ctx->p.num_rows == 1;
+    if (!single && (!coeffs || !q0_mont)) return fail(ctx, ZIP_ERR_NULL, "coeffs / q0_mont is NULL");
+    if ((rc = check_cols(ctx, cols, n_cols))) return rc;
+    Scratch ev(ctx), ends(ctx), small(ctx), dev0(ctx), dev1(ctx);
+    const int64_t *evals_d = c->evals;
+    if (evals) {
+        if ((rc = stage_evals(ctx, evals, evals_kind, (size_t)ctx->rows_local * ctx->p.row_len, ev, &evals_d))) return rc;
+    } else if (!evals_d) {
+        return fail(ctx, ZIP_ERR_NULL, "evals is NULL and the commitment retains no witness");
+    }
+    const size_t u_bytes = single ? 0 : (size_t)ctx->p.row_len * ctx->p.m_limbs * 8;
+    const size_t row_bytes = (size_t)ctx->p.row_len * hf.fl * 8;
+    const size_t colb = column_bytes(ctx);
+    // columns per group: as many as fit the hint (default 64 MiB), at least one
+    if (chunk_bytes == 0) chunk_bytes = (size_t)64 << 20;
+    size_t group = colb ? chunk_bytes / colb : n_cols;
+    if (group < 1) group = 1;
+    if (group > n_cols) group = n_cols ? n_cols : 1;
+    const size_t buf_bytes = std::max(group * colb, std::max(u_bytes, row_bytes));
+    if (buf_bytes > ctx->bounce_cap) {
+        for (auto *&b : ctx->bounce) {
+            if (b) (void)hipHostFree(b);
+            b = nullptr;
+        }
+        ctx->bounce_cap = 0;
+        for (auto *&b : ctx->bounce) {
+            hipError_t e = hipHostMalloc((void **)&b, buf_bytes, hipHostMallocDefault);
+            if (e != hipSuccess) return fail(ctx, ZIP_ERR_ALLOC, "hipHostMalloc(%zu) failed: %s", buf_bytes, hipGetErrorString(e));
+        }
+        ctx->bounce_cap = buf_bytes;
+    }
+    if ((rc = ends.get(u_bytes + row_bytes + 16))) return rc;
+    if ((rc = dev0.get(group * colb + 16))) return rc;
+    if ((rc = dev1.get(group * colb + 16))) return rc;
+    uint8_t *dev[2] = {dev0.as<uint8_t>(), dev1.as<uint8_t>()};
+    SmallInputs si;
+    if (!single) {
+        si.src[0] = coeffs;
+        si.bytes[0] = (size_t)ctx->rows_local * 8;
+    }
+    si.src[1] = single ? hf.r : q0_mont;
+    si.bytes[1] = (size_t)ctx->rows_local * hf.fl * 8;
+    si.src[2] = cols;
+    si.bytes[2] = (size_t)n_cols * 4;
+    unsigned char *sb;
+    if ((rc = stage_small(ctx, si, small, &sb))) return rc;
+    const uint32_t *cols_d = reinterpret_cast<const uint32_t *>(sb + si.off[2]);
+    // the two row combinations (they do not need the commitment) -> u' and the evaluation row
+    CombineOut o{};
+    o.uprime = single ? nullptr : ends.as<uint64_t>();
+    o.row_be = ends.as<uint8_t>() + u_bytes;
+    if ((rc = run_combine(ctx, evals_d, reinterpret_cast<const int64_t *>(sb + si.off[0]),
+                          reinterpret_cast<const uint64_t *>(sb + si.off[1]), &hf, !single, true, o)))
+        return rc;
+    hipStream_t s_copy = ctx->s_upper;  // D2H copies run beside the next group's gather
+    hipEvent_t gathered[2] = {take_dep_event(ctx), take_dep_event(ctx)};
+    hipEvent_t copied[2] = {take_dep_event(ctx), take_dep_event(ctx)};
+    for (int i = 0; i < 2; i++) { c->aux.push_back(gathered[i]); c->aux.push_back(copied[i]); }
+    // piece 1: u' (open_z.rs:110-112)
+    if (u_bytes) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->bounce[0], ends.ptr, u_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (sink(user, ctx->bounce[0], u_bytes)) return fail(ctx, ZIP_ERR_INVALID_PARAM, "the proof sink refused the stream");
+    }
+    if ((rc = wait_ready(c, ctx->stream))) return rc;
+    // pieces 2..: groups of opened columns, double buffered: gather g+1 | copy g | sink g-1
+    const size_t n_groups = n_cols ? (n_cols + group - 1) / group : 0;
+    auto launch = [&](size_t g) -> int32_t {
+        const int b = (int)(g & 1);
+        const uint32_t first = (uint32_t)(g * group), cnt = (uint32_t)std::min(group, (size_t)n_cols - first);
+        if (g >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, copied[b], 0));  // dev[b] has left the device
+        int32_t r = run_open_columns(c, cols_d + first, cnt, dev[b], 0, ctx->rows_local);
+        if (r) return r;
+        HIP_TRY(ctx, hipEventRecord(gathered[b], ctx->stream));
+        return ZIP_OK;
+    };
+    auto copy_out = [&](size_t g) -> int32_t {
+        const int b = (int)(g & 1);
+        const uint32_t first = (uint32_t)(g * group), cnt = (uint32_t)std::min(group, (size_t)n_cols - first);
+        HIP_TRY(ctx, hipStreamWaitEvent(s_copy, gathered[b], 0));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->bounce[b], dev[b], (size_t)cnt * colb, hipMemcpyDeviceToHost, s_copy));
+        HIP_TRY(ctx, hipEventRecord(copied[b], s_copy));
+        return ZIP_OK;
+    };
+    int32_t status = ZIP_OK;
+    if (n_groups) status = launch(0);
+    for (size_t g = 0; g < n_groups && status == ZIP_OK; g++) {
+        // bounce[g & 1] is free: the sink of group g-2 returned before this iteration began
+        if ((status = copy_out(g))) break;
+        if (g + 1 < n_groups && (status = launch(g + 1))) break;
+        if (hipEventSynchronize(copied[g & 1]) != hipSuccess) { status = fail(ctx, ZIP_ERR_HIP, "proof copy failed"); break; }
+        const uint32_t first = (uint32_t)(g * group), cnt = (uint32_t)std::min(group, (size_t)n_cols - first);
+        if (sink(user, ctx->bounce[g & 1], (size_t)cnt * colb))
+            status = fail(ctx, ZIP_ERR_INVALID_PARAM, "the proof sink refused the stream");
+    }
+    // drain whatever is still in flight before the scratch buffers return to the pool
+    (void)hipStreamSynchronize(s_copy);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (status) return status;
+    // last piece: the evaluation row (open_z.rs:89-90)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->bounce[0], ends.as<uint8_t>() + u_bytes, row_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (sink(user, ctx->bounce[0], row_bytes)) return fail(ctx, ZIP_ERR_INVALID_PARAM, "the proof sink refused the stream");
+    return check_timeout(ctx);
 }
 
 int32_t zip_sum_partials(zip_ctx *ctx, const uint64_t *uparts, const uint64_t *fparts, uint32_t n_parts,
