@@ -56,6 +56,8 @@ typedef struct zinc_zip_params zinc_zip_params;
 typedef struct zinc_zip_data zinc_zip_data;
 int32_t zinc_zip_setup(uint64_t poly_size, const zinc_raa_code *code, int32_t device, zinc_zip_params **out);
 void zinc_zip_params_free(zinc_zip_params *pp);
+/* setup() caches device contexts per (device, geometry, seeds); this drops the cache and its device memory */
+void zinc_zip_release_cached_contexts(void);
 void zinc_zip_params_geometry(const zinc_zip_params *pp, uint32_t *num_vars, uint32_t *num_rows, uint32_t *row_len,
                               uint32_t *codeword_len);
 /* roots_out: num_rows * 32 bytes (ignored when with_merkle == 0) */

@@ -86,6 +86,8 @@ const char *zip_strerror(int32_t code);
 /* number of visible HIP devices (0 when there is no GPU); never initialises a context */
 int32_t zip_device_count(void);
 
+/* Threading: calls on one ctx (and on its commitments) are serialised inside the library -- they
+ * share one pinned staging buffer and one set of streams; distinct contexts run concurrently. */
 int32_t zip_ctx_create(const zip_params *params, zip_ctx **out);
 void zip_ctx_destroy(zip_ctx *ctx);
 const char *zip_ctx_last_error(const zip_ctx *ctx);

@@ -156,3 +156,33 @@ def test_evaluate_matches_map_to_field_then_evaluate(pcs):
     assert orc.limbs_to_int(v) == orc.Zip(nv).mle_eval(fo, evals, orc.point_to_field(fo, point_i))
     with pytest.raises(pcs.InvalidPcsParam):
         pcs.MultilinearZip.evaluate(param, evals, field.map_to_field(point_i[:-1]), field)
+
+
+def test_concurrent_commits_share_a_cached_context(pcs):
+    """commit is callable from many threads at once in the reference (commit.rs:439-470); setup hands
+    the same cached device context to all of them, and the library serialises the calls on it."""
+    import threading
+
+    nv = 10
+    z = orc.Zip(nv, seeds=(1, 2))
+    want = {}
+    polys = [orc.splitmix64(100 + i, 1 << nv) for i in range(6)]
+    for i, p in enumerate(polys):
+        want[i] = z.commit(p)[2]
+    got, errs = {}, []
+
+    def work(i):
+        try:
+            pp = pcs.MultilinearZip.setup(1 << nv, pcs.RaaCode(1 << nv))
+            for _ in range(3):
+                _, roots = pcs.MultilinearZip.commit(pp, polys[i])
+            got[i] = roots
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(polys))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs
+    for i in range(len(polys)):
+        assert np.array_equal(got[i], want[i])

@@ -5,6 +5,7 @@
 // HIP-event measurement hooks used by bench.py.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <thread>
 
 #include <cstdarg>
 #include <cstdio>
@@ -70,6 +71,9 @@ struct zip_ctx {
     std::multimap<size_t, void *> free_blocks;
     std::map<void *, size_t> live_blocks;
     std::mutex mu;
+    // Serialises the exported calls on this ctx (and on its commitments): they share one pinned
+    // staging buffer and one set of streams.  Distinct contexts run concurrently.
+    std::recursive_mutex api_mu;
     // measurement
     bool profiling = false;
     std::vector<PendingEvent> pending;
@@ -240,6 +244,109 @@ hipEvent_t take_dep_event(zip_ctx *ctx) {
     hipEvent_t e = nullptr;
     (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     return e;
+}
+
+// ------------------------------------------------------------------ large host <-> device copies
+// hipMemcpy to or from pageable memory the runtime has not seen before first PINS it (measured:
+// a fresh 383 MiB destination costs ~100 ms, 3-4 GB/s; the same buffer reused runs at 54 GB/s).
+// The reference's calling convention hands over fresh Vecs every time, so large transfers go through
+// two library-owned pinned bounce buffers instead: PCIe copy of chunk i beside a multi-threaded
+// memcpy of chunk i-1 between the bounce buffer and the caller's memory.
+constexpr size_t kBounceBytes = (size_t)32 << 20;
+constexpr size_t kBounceThreshold = (size_t)8 << 20;
+
+int32_t ensure_bounce(zip_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->bounce_cap) return ZIP_OK;
+    for (auto *&b : ctx->bounce) {
+        if (b) (void)hipHostFree(b);
+        b = nullptr;
+    }
+    ctx->bounce_cap = 0;
+    for (auto *&b : ctx->bounce) {
+        hipError_t e = hipHostMalloc((void **)&b, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(ctx, ZIP_ERR_ALLOC, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    ctx->bounce_cap = bytes;
+    return ZIP_OK;
+}
+
+void parallel_memcpy(void *dst, const void *src, size_t bytes) {
+    if (bytes < ((size_t)4 << 20)) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    unsigned n = std::thread::hardware_concurrency();
+    n = n ? std::min(n, 8u) : 4u;
+    const size_t per = ((bytes / n) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < n; t++) {
+        const size_t lo = (size_t)t * per;
+        if (lo >= bytes) break;
+        const size_t len = std::min(per, bytes - lo);
+        th.emplace_back([=] { memcpy(static_cast<char *>(dst) + lo, static_cast<const char *>(src) + lo, len); });
+    }
+    memcpy(dst, src, std::min(per, bytes));
+    for (auto &x : th) x.join();
+}
+
+// dst_h (pageable) <- src_d, ordered after everything enqueued on `after` so far.  Synchronous.
+int32_t copy_d2h_bounced(zip_ctx *ctx, void *dst_h, const void *src_d, size_t bytes, hipStream_t after) {
+    if (bytes < kBounceThreshold) {
+        HIP_TRY(ctx, hipMemcpyAsync(dst_h, src_d, bytes, hipMemcpyDeviceToHost, after));
+        HIP_TRY(ctx, hipStreamSynchronize(after));
+        return ZIP_OK;
+    }
+    int32_t rc = ensure_bounce(ctx, kBounceBytes);
+    if (rc) return rc;
+    const size_t chunk = ctx->bounce_cap;
+    const size_t n = (bytes + chunk - 1) / chunk;
+    hipEvent_t ev[2] = {take_dep_event(ctx), take_dep_event(ctx)};
+    auto issue = [&](size_t i) -> int32_t {
+        const size_t off = i * chunk, len = std::min(chunk, bytes - off);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->bounce[i & 1], static_cast<const char *>(src_d) + off, len, hipMemcpyDeviceToHost, after));
+        HIP_TRY(ctx, hipEventRecord(ev[i & 1], after));
+        return ZIP_OK;
+    };
+    rc = issue(0);
+    for (size_t i = 0; i < n && rc == ZIP_OK; i++) {
+        if (i + 1 < n) rc = issue(i + 1);  // bounce[(i+1)&1] was drained in iteration i-1
+        if (rc) break;
+        if (hipEventSynchronize(ev[i & 1]) != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "device-to-host copy failed"); break; }
+        const size_t off = i * chunk, len = std::min(chunk, bytes - off);
+        parallel_memcpy(static_cast<char *>(dst_h) + off, ctx->bounce[i & 1], len);
+    }
+    (void)hipStreamSynchronize(after);
+    ctx->dep_event_pool.push_back(ev[0]);
+    ctx->dep_event_pool.push_back(ev[1]);
+    return rc;
+}
+
+// dst_d <- src_h (pageable) on `st`.  Returns once the caller's buffer has been read completely
+// (the last chunk may still be in flight from the bounce buffer; later work on `st` is ordered).
+int32_t copy_h2d_bounced(zip_ctx *ctx, void *dst_d, const void *src_h, size_t bytes, hipStream_t st) {
+    if (bytes < kBounceThreshold) {
+        HIP_TRY(ctx, hipMemcpyAsync(dst_d, src_h, bytes, hipMemcpyHostToDevice, st));
+        return ZIP_OK;
+    }
+    int32_t rc = ensure_bounce(ctx, kBounceBytes);
+    if (rc) return rc;
+    const size_t chunk = ctx->bounce_cap;
+    const size_t n = (bytes + chunk - 1) / chunk;
+    hipEvent_t ev[2] = {take_dep_event(ctx), take_dep_event(ctx)};
+    for (size_t i = 0; i < n; i++) {
+        const size_t off = i * chunk, len = std::min(chunk, bytes - off);
+        if (i >= 2 && hipEventSynchronize(ev[i & 1]) != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "host-to-device copy failed"); break; }
+        parallel_memcpy(ctx->bounce[i & 1], static_cast<const char *>(src_h) + off, len);
+        hipError_t e = hipMemcpyAsync(static_cast<char *>(dst_d) + off, ctx->bounce[i & 1], len, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipEventRecord(ev[i & 1], st);
+        if (e != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "host-to-device copy failed: %s", hipGetErrorString(e)); break; }
+    }
+    // the bounce buffers are reused by the next call: wait for the tail
+    (void)hipEventSynchronize(ev[0]);
+    (void)hipEventSynchronize(ev[1]);
+    ctx->dep_event_pool.push_back(ev[0]);
+    ctx->dep_event_pool.push_back(ev[1]);
+    return rc;
 }
 
 // Orders `stream` after the whole commit that produces `c`.
@@ -431,7 +538,7 @@ int32_t stage_evals(zip_ctx *ctx, const int64_t *evals, zip_mem_kind kind, size_
     }
     int32_t rc = tmp.get(n * 8);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(tmp.ptr, evals, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = copy_h2d_bounced(ctx, tmp.ptr, evals, n * 8, ctx->stream))) return rc;
     *dev = tmp.as<int64_t>();
     return ZIP_OK;
 }
@@ -449,7 +556,10 @@ int32_t run_combine_fl(zip_ctx *ctx, hipStream_t st, const int64_t *evals_d, con
                        const uint64_t *q0_dv, const HostField *hf, bool do_int, bool do_field, const CombineOut &out) {
     const uint32_t R = ctx->rows_local, C = ctx->p.row_len;
     const uint32_t bx = (C + 255) / 256;
+    // row chunks: enough workgroups to fill the chip, but few enough that the (latency-bound) fold of
+    // the partials in combine_finalize_kernel stays short -- 128 chunks at 2^20 cost 0.32 ms there
     uint32_t chunks = 512 / bx;
+    if (chunks > 32) chunks = 32;
     if (chunks < 1) chunks = 1;
     if (chunks > R) chunks = R;
     const uint32_t rpc = (R + chunks - 1) / chunks;
@@ -600,8 +710,8 @@ int32_t check_timeout(zip_ctx *ctx) {
 
 int32_t deliver(zip_ctx *ctx, void *dst, zip_mem_kind kind, const void *src_d, size_t bytes) {
     if (kind == ZIP_MEM_HOST) {
-        HIP_TRY(ctx, hipMemcpyAsync(dst, src_d, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        int32_t rc = copy_d2h_bounced(ctx, dst, src_d, bytes, ctx->stream);
+        if (rc) return rc;
         return check_timeout(ctx);
     } else if (dst != src_d) {
         HIP_TRY(ctx, hipMemcpyAsync(dst, src_d, bytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -919,6 +1029,7 @@ const char *zip_ctx_last_error(const zip_ctx *ctx) { return ctx ? ctx->last_erro
 
 int32_t zip_ctx_synchronize(zip_ctx *ctx) {
     if (!ctx) return ZIP_ERR_NULL;
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
     if (ctx->s_commit) HIP_TRY(ctx, hipStreamSynchronize(ctx->s_commit));
     if (ctx->s_upper) HIP_TRY(ctx, hipStreamSynchronize(ctx->s_upper));
     if (ctx->s_aux) HIP_TRY(ctx, hipStreamSynchronize(ctx->s_aux));
@@ -933,6 +1044,7 @@ int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_k
     if (!ctx || !out) return ZIP_ERR_NULL;
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
     const uint32_t R = ctx->rows_local, C = ctx->p.row_len, cw = ctx->p.codeword_len;
     if (n_evals != (size_t)R * C)
         return fail(ctx, ZIP_ERR_SHAPE,
@@ -956,8 +1068,7 @@ int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_k
         if (evals_kind == ZIP_MEM_HOST) {
             c->evals_bytes = n_evals * 8;
             if ((rc = pool_alloc(ctx, c->evals_bytes, (void **)&c->evals))) break;
-            hipError_t e = hipMemcpyAsync(c->evals, evals, c->evals_bytes, hipMemcpyHostToDevice, ctx->s_commit);
-            if (e != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "witness upload failed: %s", hipGetErrorString(e)); break; }
+            if ((rc = copy_h2d_bounced(ctx, c->evals, evals, c->evals_bytes, ctx->s_commit))) break;
             evals_d = c->evals;
         }
         // ---- ONE persistent commit launch on s_commit; its chunks are consumed on s_upper ----
@@ -1023,6 +1134,7 @@ int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_k
 
 void zip_commitment_free(zip_commitment *c) {
     if (!c) return;
+    std::lock_guard<std::recursive_mutex> api_lock(c->ctx->api_mu);
     // nothing may still be reading or writing the buffers when they return to the pool
     if (c->done) {
         (void)hipEventSynchronize(c->done);
@@ -1041,6 +1153,7 @@ void zip_commitment_free(zip_commitment *c) {
 
 int32_t zip_commitment_device_ptrs(zip_commitment *c, uint64_t **rows, uint8_t **layers, uint8_t **roots) {
     if (!c) return ZIP_ERR_NULL;
+    std::lock_guard<std::recursive_mutex> api_lock(c->ctx->api_mu);
     // work enqueued on the ctx stream (zip_ctx_stream) after this call sees complete data
     int32_t rc_ = wait_ready(c, c->ctx->stream);
     if (rc_) return rc_;
@@ -1054,12 +1167,16 @@ int32_t zip_commit_download(zip_commitment *c, uint64_t *rows_out, uint8_t *laye
     if (!c) return ZIP_ERR_NULL;
     zip_ctx *ctx = c->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
     const uint32_t R = ctx->rows_local, cw = ctx->p.codeword_len;
     {
         int32_t rc_ = wait_ready(c, ctx->stream);
         if (rc_) return rc_;
     }
-    if (rows_out) HIP_TRY(ctx, hipMemcpyAsync(rows_out, c->rows, c->rows_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (rows_out) {
+        int32_t rc_ = copy_d2h_bounced(ctx, rows_out, c->rows, c->rows_bytes, ctx->stream);
+        if (rc_) return rc_;
+    }
     if (layers_out) {
         if (!c->layers) return fail(ctx, ZIP_ERR_INVALID_PARAM, "commitment has no Merkle trees (commit_no_merkle)");
         const size_t w = ((size_t)2 * cw - 2) * 32;
@@ -1080,6 +1197,7 @@ int32_t zip_commitment_upload(zip_ctx *ctx, const uint64_t *rows, const uint8_t 
     if (!ctx || !out || !rows) return ZIP_ERR_NULL;
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
     const uint32_t R = ctx->rows_local, cw = ctx->p.codeword_len;
     zip_commitment *c = new (std::nothrow) zip_commitment();
     if (!c) return ZIP_ERR_ALLOC;
@@ -1119,6 +1237,7 @@ int32_t zip_open_testing(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_
                          uint64_t *uprime_out, zip_mem_kind out_kind) {
     if (!ctx || !coeffs || !uprime_out) return ZIP_ERR_NULL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
     Scratch ev(ctx), res(ctx);
     const int64_t *evals_d;
     int32_t rc;
@@ -1150,6 +1269,7 @@ int32_t zip_open_columns(zip_commitment *c, const uint32_t *cols, uint32_t n_col
     if (!c || !cols || !wire_out) return ZIP_ERR_NULL;
     zip_ctx *ctx = c->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
     if (!c->layers) return fail(ctx, ZIP_ERR_INVALID_PARAM, "commitment has no Merkle trees (commit_no_merkle)");
     const size_t bytes = (size_t)n_cols * column_bytes(ctx);
     Scratch res(ctx);
@@ -1176,6 +1296,7 @@ int32_t zip_open_eval(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_kin
                       const zip_field *field, uint64_t *row_out, zip_mem_kind out_kind) {
     if (!ctx || !row_out) return ZIP_ERR_NULL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
     HostField hf;
     int32_t rc;
     if ((rc = make_field(ctx, field, &hf))) return rc;
@@ -1222,6 +1343,7 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
     if (!c || !proof_out || (n_cols && !cols)) return ZIP_ERR_NULL;
     zip_ctx *ctx = c->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
     if (ctx->rows_local != ctx->p.num_rows)
         return fail(ctx, ZIP_ERR_INVALID_PARAM, "zip_open needs an unsharded ctx; use the per-phase calls on a row shard");
     if (!c->layers) return fail(ctx, ZIP_ERR_INVALID_PARAM, "commitment has no Merkle trees (commit_no_merkle)");
@@ -1297,6 +1419,7 @@ int32_t zip_verify(zip_ctx *ctx, const uint8_t *roots, const uint8_t *proof, zip
     if (!ctx || !roots || !proof || !report || !eval_mont || (n_cols && !cols)) return ZIP_ERR_NULL;
     memset(report, 0, sizeof *report);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
     if (ctx->rows_local != ctx->p.num_rows)
         return fail(ctx, ZIP_ERR_INVALID_PARAM, "zip_verify needs an unsharded ctx");
     HostField hf;
@@ -1316,7 +1439,7 @@ int32_t zip_verify(zip_ctx *ctx, const uint8_t *roots, const uint8_t *proof, zip
     const uint8_t *proof_d = proof;
     if (proof_kind == ZIP_MEM_HOST) {
         if ((rc = pbuf.get(need))) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(pbuf.ptr, proof, need, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = copy_h2d_bounced(ctx, pbuf.ptr, proof, need, ctx->stream))) return rc;
         proof_d = pbuf.as<uint8_t>();
     }
     // q_1 of a one-column matrix is empty in the reference (pcs/utils.rs:253-276): <row, q1> is then 0
@@ -1372,6 +1495,7 @@ int32_t zip_mle_eval(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_kind
                      const uint64_t *q1_mont, const zip_field *field, uint64_t *value_out) {
     if (!ctx || !value_out) return ZIP_ERR_NULL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
     if (ctx->rows_local != ctx->p.num_rows)
         return fail(ctx, ZIP_ERR_INVALID_PARAM, "zip_mle_eval needs an unsharded ctx");
     HostField hf;
@@ -1413,6 +1537,7 @@ int32_t zip_mle_eval(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_kind
 int32_t zip_field_map_int256(zip_ctx *ctx, const uint64_t *values, uint32_t n, const zip_field *field, uint64_t *out) {
     if (!ctx || !values || !out) return ZIP_ERR_NULL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
     HostField hf, hq;
     int32_t rc;
     if ((rc = make_field(ctx, field, &hf))) return rc;
@@ -1437,6 +1562,7 @@ int32_t zip_open_stream(zip_commitment *c, const int64_t *evals, zip_mem_kind ev
     if (!c || !sink || (n_cols && !cols)) return ZIP_ERR_NULL;
     zip_ctx *ctx = c->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
     if (ctx->rows_local != ctx->p.num_rows)
         return fail(ctx, ZIP_ERR_INVALID_PARAM, "zip_open_stream needs an unsharded ctx");
     if (!c->layers) return fail(ctx, ZIP_ERR_INVALID_PARAM, "commitment has no Merkle trees (commit_no_merkle)");
@@ -1462,18 +1588,7 @@ int32_t zip_open_stream(zip_commitment *c, const int64_t *evals, zip_mem_kind ev
     if (group < 1) group = 1;
     if (group > n_cols) group = n_cols ? n_cols : 1;
     const size_t buf_bytes = std::max(group * colb, std::max(u_bytes, row_bytes));
-    if (buf_bytes > ctx->bounce_cap) {
-        for (auto *&b : ctx->bounce) {
-            if (b) (void)hipHostFree(b);
-            b = nullptr;
-        }
-        ctx->bounce_cap = 0;
-        for (auto *&b : ctx->bounce) {
-            hipError_t e = hipHostMalloc((void **)&b, buf_bytes, hipHostMallocDefault);
-            if (e != hipSuccess) return fail(ctx, ZIP_ERR_ALLOC, "hipHostMalloc(%zu) failed: %s", buf_bytes, hipGetErrorString(e));
-        }
-        ctx->bounce_cap = buf_bytes;
-    }
+    if ((rc = ensure_bounce(ctx, buf_bytes))) return rc;
     if ((rc = ends.get(u_bytes + row_bytes + 16))) return rc;
     if ((rc = dev0.get(group * colb + 16))) return rc;
     if ((rc = dev1.get(group * colb + 16))) return rc;
@@ -1553,6 +1668,7 @@ int32_t zip_sum_partials(zip_ctx *ctx, const uint64_t *uparts, const uint64_t *f
                          const zip_field *field, uint64_t *uprime_out, uint64_t *row_out) {
     if (!ctx) return ZIP_ERR_NULL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
     if ((uparts && !uprime_out) || (fparts && !row_out)) return ZIP_ERR_NULL;
     HostField hf;
     hf.fl = 4;
@@ -1645,6 +1761,7 @@ int32_t zip_ctx_set_profiling(zip_ctx *ctx, int32_t on) {
 int32_t zip_ctx_profile_read(zip_ctx *ctx, zip_kernel_time *out, uint32_t cap) {
     if (!ctx) return ZIP_ERR_NULL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (auto &pe : ctx->pending) {
         float ms = 0.f;

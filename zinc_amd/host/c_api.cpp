@@ -134,6 +134,7 @@ int32_t zinc_zip_setup(uint64_t poly_size, const zinc_raa_code *code, int32_t de
     });
 }
 void zinc_zip_params_free(zinc_zip_params *pp) { delete pp; }
+void zinc_zip_release_cached_contexts(void) { MultilinearZip::release_cached_contexts(); }
 void zinc_zip_params_geometry(const zinc_zip_params *pp, uint32_t *num_vars, uint32_t *num_rows, uint32_t *row_len,
                               uint32_t *codeword_len) {
     *num_vars = pp->pp.num_vars;

@@ -3,8 +3,26 @@
 #include "zinc_zip.hpp"
 
 #include <algorithm>
+#include <list>
+#include <mutex>
+
+#include <sys/mman.h>
 
 namespace zinc {
+
+void *byte_stream_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes >= ((size_t)16 << 20)) {
+        if (posix_memalign(&p, (size_t)2 << 20, bytes) != 0) throw std::bad_alloc();
+#ifdef MADV_HUGEPAGE
+        (void)madvise(p, bytes, MADV_HUGEPAGE);
+#endif
+        return p;
+    }
+    p = std::malloc(bytes ? bytes : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
 
 using u128 = unsigned __int128;
 
@@ -505,6 +523,28 @@ static void check(zip_ctx *ctx, int32_t rc, const char *what) {
     throw ZipError(ZipError::Device, msg);
 }
 
+namespace {
+struct CtxKey {
+    int device;
+    uint32_t num_vars, row_len, rep;
+    uint64_t seed1, seed2;
+    bool operator==(const CtxKey &o) const {
+        return device == o.device && num_vars == o.num_vars && row_len == o.row_len && rep == o.rep &&
+               seed1 == o.seed1 && seed2 == o.seed2;
+    }
+};
+constexpr size_t kCtxCacheSize = 4;
+std::mutex &ctx_cache_mu() {
+    static std::mutex m;
+    return m;
+}
+std::list<std::pair<CtxKey, std::shared_ptr<zip_ctx>>> &ctx_cache() {
+    static std::list<std::pair<CtxKey, std::shared_ptr<zip_ctx>>> c;
+    return c;
+}
+
+}  // namespace
+
 MultilinearZipParams MultilinearZip::setup(uint64_t poly_size, const RaaCode &code, int device) {
     if (poly_size == 0 || (poly_size & (poly_size - 1))) throw std::logic_error("assertion failed: poly_size.is_power_of_two()");
     MultilinearZipParams pp;
@@ -514,6 +554,19 @@ MultilinearZipParams MultilinearZip::setup(uint64_t poly_size, const RaaCode &co
     // The shim's job: expand the two seeds once (the reference re-runs the shuffle for every row).
     pp.perm1 = shuffle_seeded_perm(code.perm_1_seed, code.codeword_len());
     pp.perm2 = shuffle_seeded_perm(code.perm_2_seed, code.codeword_len());
+    // cached device context for this (device, geometry, seeds)
+    const CtxKey key{device, pp.num_vars, code.row_len, code.repetition_factor, code.perm_1_seed, code.perm_2_seed};
+    {
+        std::lock_guard<std::mutex> g(ctx_cache_mu());
+        auto &cache = ctx_cache();
+        for (auto it = cache.begin(); it != cache.end(); ++it) {
+            if (it->first == key) {
+                pp.ctx = it->second;
+                cache.splice(cache.begin(), cache, it);  // most recently used first
+                return pp;
+            }
+        }
+    }
     zip_params zp{};
     zp.num_vars = pp.num_vars;
     zp.row_len = code.row_len;
@@ -529,7 +582,18 @@ MultilinearZipParams MultilinearZip::setup(uint64_t poly_size, const RaaCode &co
     zip_ctx *ctx = nullptr;
     check(nullptr, zip_ctx_create(&zp, &ctx), "zip_ctx_create");
     pp.ctx = std::shared_ptr<zip_ctx>(ctx, zip_ctx_destroy);
+    {
+        std::lock_guard<std::mutex> g(ctx_cache_mu());
+        auto &cache = ctx_cache();
+        cache.emplace_front(key, pp.ctx);
+        while (cache.size() > kCtxCacheSize) cache.pop_back();
+    }
     return pp;
+}
+
+void MultilinearZip::release_cached_contexts() {
+    std::lock_guard<std::mutex> g(ctx_cache_mu());
+    ctx_cache().clear();
 }
 
 // validate_input (pcs/utils.rs:24-58)
@@ -602,7 +666,7 @@ void MultilinearZip::open(const MultilinearZipParams &pp, const int64_t *evals, 
     const zip_field zf = field.to_abi();
     const size_t len = zip_proof_len(ctx, (uint32_t)cols.size(), field.limbs);
     const size_t at = transcript.stream.size();
-    transcript.stream.resize(at + len);
+    transcript.stream.resize(at + len);  // uninitialised (ByteStream); the library's copy threads touch the pages
     check(ctx,
           zip_open(commit_data.handle.get(), evals, ZIP_MEM_HOST, coeffs.empty() ? nullptr : coeffs.data(), cols.data(),
                    (uint32_t)cols.size(), q0.empty() ? nullptr : q0.data(), &zf, transcript.stream.data() + at,

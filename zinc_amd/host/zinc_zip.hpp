@@ -20,8 +20,12 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <new>
+#include <type_traits>
+#include <utility>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -29,6 +33,30 @@
 #include "zip_hip.h"
 
 namespace zinc {
+
+// Byte vector whose resize() leaves new bytes uninitialised: the proof stream of a 2^24 witness is
+// 1.74 GiB that the device overwrites entirely, and value-initialising it first costs a full extra
+// pass over fresh pages on the host.
+template <class T>
+struct default_init_allocator {
+    using value_type = T;
+    template <class U> struct rebind { using other = default_init_allocator<U>; };
+    default_init_allocator() = default;
+    template <class U> default_init_allocator(const default_init_allocator<U> &) {}
+    // Large blocks are 2 MiB aligned and marked for transparent huge pages: first-touch faults
+    // (the kernel zero-filling fresh pages) are what bounds the arrival of a proof in host memory.
+    T *allocate(size_t n) { return static_cast<T *>(big_alloc(n * sizeof(T))); }
+    void deallocate(T *p, size_t) { std::free(p); }
+    template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+    bool operator==(const default_init_allocator &) const { return true; }
+    bool operator!=(const default_init_allocator &) const { return false; }
+    static void *big_alloc(size_t bytes);
+};
+void *byte_stream_alloc(size_t bytes);
+template <class T>
+void *default_init_allocator<T>::big_alloc(size_t bytes) { return byte_stream_alloc(bytes); }
+using ByteStream = std::vector<uint8_t, default_init_allocator<uint8_t>>;
 
 constexpr uint32_t kMaxLimbs = 8;
 using Limbs = std::array<uint64_t, kMaxLimbs>;  // little-endian, unused limbs zero
@@ -142,7 +170,7 @@ struct RaaCode {
 // PcsTranscript (src/zip/pcs_transcript.rs:19-48): Fiat-Shamir state + the proof byte stream.
 struct PcsTranscript {
     KeccakTranscript fs_transcript;
-    std::vector<uint8_t> stream;
+    ByteStream stream;
     size_t read_pos = 0;  // Cursor position of the reading side (PcsTranscript::from_proof, :28-35)
 
     static PcsTranscript from_proof(const uint8_t *proof, size_t len) {
@@ -154,7 +182,7 @@ struct PcsTranscript {
     void write_field_elements(const FieldConfig &f, const Limbs *elems, size_t n);  // :76-113
     void append(const uint8_t *bytes, size_t n) { stream.insert(stream.end(), bytes, bytes + n); }
     size_t squeeze_challenge_idx(const FieldConfig &f, size_t cap);                // :174-179
-    std::vector<uint8_t> into_proof() { return std::move(stream); }
+    ByteStream into_proof() { return std::move(stream); }
 };
 
 // MultilinearZipParams (structs.rs:13-18) + the device context that serves this geometry.
@@ -176,8 +204,12 @@ struct MultilinearZipCommitment {
 };
 
 struct MultilinearZip {
-    // structs.rs:79-91
+    // structs.rs:79-91.  Device contexts (streams, pinned staging, the device memory pool, the
+    // uploaded permutation tables) are cached per (device, geometry, seeds): ZincProver calls setup
+    // for every proof, and a cold context costs more than a 2^20 commit.  The most recent few stay
+    // alive; release_cached_contexts() drops them (and their device memory).
     static MultilinearZipParams setup(uint64_t poly_size, const RaaCode &code, int device = 0);
+    static void release_cached_contexts();
     // commit.rs:50-87.  poly_num_vars is DenseMultilinearExtension::num_vars of the caller's polynomial.
     static std::pair<MultilinearZipData, MultilinearZipCommitment> commit(const MultilinearZipParams &pp,
                                                                           const int64_t *evals, size_t n_evals,
@@ -206,7 +238,7 @@ struct MultilinearZip {
 struct ZipProof {
     MultilinearZipCommitment z_comm;
     Limbs v{};
-    std::vector<uint8_t> pcs_proof;
+    ByteStream pcs_proof;
 };
 ZipProof commit_z_mle_and_prove_evaluation(const LinearCodeSpec &lc_spec, const int64_t *z_evals, size_t m,
                                            const Limbs *r_y, size_t r_y_len, KeccakTranscript &transcript,

@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "zinc_pcs_transcript_free", "zinc_pcs_transcript_len", "zinc_pcs_transcript_copy",
     "zinc_pcs_transcript_probe", "zinc_zip_open", "zinc_pcs_transcript_from_proof", "zinc_pcs_transcript_position",
     "zinc_zip_verify", "zinc_zip_evaluate", "zinc_commit_z_mle_and_prove_evaluation", "zinc_zip_proof_len",
-    "zinc_zip_proof_num_roots", "zinc_zip_proof_read", "zinc_zip_proof_free",
+    "zinc_zip_proof_num_roots", "zinc_zip_proof_read", "zinc_zip_proof_free", "zinc_zip_release_cached_contexts",
 )
 
 
