@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libzip_hip.so")
+LIB_PATH = os.environ.get("ZIP_HIP_LIB_PATH") or os.path.join(_PKG, "lib", "libzip_hip.so")  # override: A/B runs of two builds
 
 ZIP_OK = 0
 ZIP_ERR_INVALID_PARAM = -1
