@@ -106,6 +106,13 @@ size_t zinc_zip_proof_num_roots(const zinc_zip_proof *p);
 void zinc_zip_proof_read(const zinc_zip_proof *p, uint8_t *roots_out, uint64_t *v_out, uint8_t *pcs_proof_out);
 void zinc_zip_proof_free(zinc_zip_proof *p);
 
+/* MLSumcheck::prove_as_subprotocol with comb_fn = product (src/sumcheck.rs:56-112, zinc/prover.rs:297-302).
+ * mles: n_mles host tables of 2^nvars elements (Montgomery limbs).  msgs_out: nvars * (degree+1) * limbs;
+ * randomness_out: nvars * limbs. */
+int32_t zinc_sumcheck_prove_product(zinc_transcript *transcript, const uint64_t *const *mles, uint32_t n_mles,
+                                    uint32_t nvars, uint32_t degree, const uint64_t *modulus, uint32_t limbs,
+                                    int32_t device, uint64_t *msgs_out, uint64_t *randomness_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -198,6 +198,25 @@ int32_t zip_verify(zip_ctx *ctx, const uint8_t *roots, const uint8_t *proof, zip
                    const uint64_t *q1_mont, const uint64_t *eval_mont, const zip_field *field,
                    zip_verify_report *report);
 
+/* ---- sumcheck prover for a product of MLEs ---------------------
+ * IPForMLSumcheck::prove_round (src/sumcheck/prover.rs:62-180) with comb_fn(vals) = vals[0] * vals[1] * ...
+ * (ZincProver's second sumcheck, src/zinc/prover.rs:297-302), one call per round; the caller keeps the
+ * transcript (MLSumcheck::prove_as_subprotocol, src/sumcheck.rs:56-112: absorb the evaluations, squeeze
+ * the challenge, absorb it, hand it to the next round).
+ *   mles      n_mles (1..4) tables of 2^num_vars field elements, Montgomery limbs, variable 0 = least
+ *             significant index bit; HOST tables are copied, DEVICE tables are read in place (never
+ *             written) and must outlive the handle
+ *   degree    1..4: the round polynomial is returned as its values at 0..degree (ProverMsg.evaluations)
+ *   r_prev    the verifier's challenge for the previous round (NULL in round 1): the tables are folded
+ *             with it (fix_variables, src/poly_f/mle/dense.rs:142-168) in the same pass
+ *   evaluations_out  HOST, (degree + 1) * field->limbs limbs */
+typedef struct zip_sumcheck zip_sumcheck;
+int32_t zip_sumcheck_init(int32_t device, const uint64_t *const *mles, zip_mem_kind kind, uint32_t n_mles,
+                          uint32_t num_vars, uint32_t degree, const zip_field *field, zip_sumcheck **out);
+int32_t zip_sumcheck_round(zip_sumcheck *s, const uint64_t *r_prev, uint64_t *evaluations_out);
+const char *zip_sumcheck_last_error(const zip_sumcheck *s);
+void zip_sumcheck_free(zip_sumcheck *s);
+
 /* Diagnostic: FieldMap for Int<4> (src/conversion.rs:86-100) of n arbitrary 256-bit values, as the
  * verifier applies it to column entries.  values: HOST n*4 limbs; out: HOST n*limbs Montgomery limbs. */
 int32_t zip_field_map_int256(zip_ctx *ctx, const uint64_t *values, uint32_t n, const zip_field *field, uint64_t *out);

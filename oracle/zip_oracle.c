@@ -1210,3 +1210,72 @@ void orc_mle_eval_field(const orc_field *f, const uint64_t *evals, uint32_t eval
     memcpy(out, acc, 8 * fl);
     free(eq);
 }
+
+/* ------------------------------------------------------------------ sumcheck prover (product) */
+int orc_sumcheck_prove_product(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint32_t nvars,
+                               uint32_t degree, orc_keccak *tr, uint64_t *msgs_out,
+                               uint64_t *randomness_out) {
+    const uint32_t fl = f->fl;
+    if (nvars == 0 || n_mles == 0 || n_mles > 8 || degree > 8) return ORC_ERR_PARAM;
+    const size_t n = (size_t)1 << nvars;
+    uint64_t t[ORC_MAX_FL];
+    /* sumcheck.rs:64-76: nvars and degree enter the transcript as field elements (u128 map) */
+    orc_field_from_u128(f, nvars, 0, t);
+    orc_tr_absorb_field(tr, f, t);
+    orc_field_from_u128(f, degree, 0, t);
+    orc_tr_absorb_field(tr, f, t);
+    for (uint32_t round = 1; round <= nvars; round++) {
+        const size_t half = (size_t)1 << (nvars - round);
+        if (round > 1) { /* prover.rs:68-86: fix the next variable at the previous challenge */
+            const uint64_t *r = randomness_out + (size_t)fl * (round - 2);
+            for (uint32_t k = 0; k < n_mles; k++) {
+                uint64_t *poly = mles + (size_t)k * n * fl;
+                for (size_t b = 0; b < 2 * half; b++) { /* dense.rs:155-164 */
+                    uint64_t left[ORC_MAX_FL], a[ORC_MAX_FL];
+                    memcpy(left, poly + (2 * b) * fl, 8 * fl);
+                    memcpy(a, poly + (2 * b + 1) * fl, 8 * fl);
+                    orc_field_sub(f, a, left);
+                    orc_field_mul(f, a, r);
+                    orc_field_add(f, left, a);
+                    memcpy(poly + b * fl, left, 8 * fl);
+                }
+            }
+        }
+        /* prover.rs:119-156: evaluations of the round polynomial at 0..degree */
+        uint64_t evals[9][ORC_MAX_FL];
+        memset(evals, 0, sizeof evals);
+        for (size_t b = 0; b < half; b++) {
+            uint64_t v0[8][ORC_MAX_FL], vals[8][ORC_MAX_FL], step[8][ORC_MAX_FL], prod[ORC_MAX_FL];
+            for (uint32_t k = 0; k < n_mles; k++)
+                memcpy(v0[k], mles + ((size_t)k * n + 2 * b) * fl, 8 * fl);
+            memcpy(prod, v0[0], 8 * fl);
+            for (uint32_t k = 1; k < n_mles; k++) orc_field_mul(f, prod, v0[k]);
+            orc_field_add(f, evals[0], prod);
+            if (degree > 0) {
+                for (uint32_t k = 0; k < n_mles; k++) {
+                    memcpy(vals[k], mles + ((size_t)k * n + 2 * b + 1) * fl, 8 * fl);
+                    memcpy(step[k], vals[k], 8 * fl);
+                    orc_field_sub(f, step[k], v0[k]);
+                }
+                memcpy(prod, vals[0], 8 * fl);
+                for (uint32_t k = 1; k < n_mles; k++) orc_field_mul(f, prod, vals[k]);
+                orc_field_add(f, evals[1], prod);
+                for (uint32_t e = 2; e <= degree; e++) {
+                    for (uint32_t k = 0; k < n_mles; k++) orc_field_add(f, vals[k], step[k]);
+                    memcpy(prod, vals[0], 8 * fl);
+                    for (uint32_t k = 1; k < n_mles; k++) orc_field_mul(f, prod, vals[k]);
+                    orc_field_add(f, evals[e], prod);
+                }
+            }
+        }
+        uint64_t *msg = msgs_out + (size_t)(round - 1) * (degree + 1) * fl;
+        for (uint32_t e = 0; e <= degree; e++) {
+            memcpy(msg + (size_t)e * fl, evals[e], 8 * fl);
+            orc_tr_absorb_field(tr, f, evals[e]); /* sumcheck.rs:100 absorb_slice */
+        }
+        uint64_t *r = randomness_out + (size_t)fl * (round - 1);
+        orc_tr_get_challenge(tr, f, r);  /* sample_round, verifier.rs:150-154 */
+        orc_tr_absorb_field(tr, f, r);   /* sumcheck.rs:103 */
+    }
+    return ORC_OK;
+}

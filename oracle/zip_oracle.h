@@ -179,6 +179,17 @@ int orc_verify(const orc_params *p, const orc_field *f, const uint8_t *roots,
 void orc_mle_eval_field(const orc_field *f, const uint64_t *evals, uint32_t eval_limbs,
                         uint32_t num_vars, const uint64_t *point, uint64_t *out);
 
+/* MLSumcheck::prove_as_subprotocol (src/sumcheck.rs:56-112) with prove_round
+ * (src/sumcheck/prover.rs:62-180) and fix_variables (src/poly_f/mle/dense.rs:142-168) for the
+ * combination function comb_fn(vals) = vals[0] * vals[1] * ... (ZincProver's second sumcheck,
+ * src/zinc/prover.rs:300).  mles: n_mles tables of 2^nvars field elements (Montgomery limbs),
+ * consumed in place.  msgs_out: nvars * (degree + 1) elements (ProverMsg.evaluations per round);
+ * randomness_out: nvars elements (ProverState.randomness).  Returns ORC_ERR_PARAM for nvars == 0
+ * (the reference returns an empty proof there). */
+int orc_sumcheck_prove_product(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint32_t nvars,
+                               uint32_t degree, orc_keccak *transcript, uint64_t *msgs_out,
+                               uint64_t *randomness_out);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

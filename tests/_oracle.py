@@ -166,6 +166,30 @@ def get_challenge(k: Keccak, f: Field) -> int:
     return limbs_to_int(out[: f.fl])
 
 
+def absorb_field(k: Keccak, f: Field, value_mont: int):
+    v = (C.c_uint64 * ORC_MAX_FL)(*int_to_limbs(value_mont, f.fl))
+    lib().orc_tr_absorb_field(C.byref(k), C.byref(f), v)
+
+
+def field_from_u128(f: Field, value: int) -> int:
+    out = (C.c_uint64 * ORC_MAX_FL)()
+    lib().orc_field_from_u128(C.byref(f), C.c_uint64(value & (2**64 - 1)), C.c_uint64(value >> 64), out)
+    return limbs_to_int(out[: f.fl])
+
+
+def sumcheck_prove_product(f: Field, mles: np.ndarray, degree: int, transcript: Keccak):
+    """MLSumcheck::prove_as_subprotocol with comb_fn = product.  mles: [K, 2^nv, fl] Montgomery limbs (copied).
+    Returns (msgs [nv, degree+1, fl], randomness [nv, fl])."""
+    m = np.ascontiguousarray(mles, dtype=np.uint64).copy()
+    K, n, fl = m.shape
+    nv = n.bit_length() - 1
+    msgs = np.zeros((nv, degree + 1, fl), dtype=np.uint64)
+    rand = np.zeros((nv, fl), dtype=np.uint64)
+    rc = lib().orc_sumcheck_prove_product(C.byref(f), _u64p(m), K, nv, degree, C.byref(transcript), _u64p(msgs), _u64p(rand))
+    assert rc == 0, rc
+    return msgs, rand
+
+
 def build_eq_x_r(f: Field, r: np.ndarray) -> np.ndarray:
     nvars = r.shape[0]
     out = np.zeros((1 << nvars, f.fl), dtype=np.uint64)

@@ -1,0 +1,99 @@
+"""GPU: the product sumcheck prover (zip_sumcheck_*) against the oracle's
+MLSumcheck::prove_as_subprotocol, round messages and challenges bit for bit."""
+import numpy as np
+import pytest
+
+import _oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+BENCH_MODULUS = 106319353542452952636349991594949358997917625194731877894581586278529202198383
+TEST_MODULUS_2 = 57316695564490278656402085503
+MOD_NO_SPARE = (1 << 256) - 189
+MOD_3LIMB = (1 << 190) - 11 * (1 << 64) - 59
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from zinc_amd import cabi, pcs
+
+    if cabi.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu tests must run on the MI355X box")
+    return cabi, pcs
+
+
+def _tables(f, fl, modulus, K, nv, seed):
+    """K tables of 2^nv canonical field elements (Montgomery limbs): the witness-like one from i64, the rest random"""
+    rng = np.random.default_rng(seed)
+    n = 1 << nv
+    out = np.zeros((K, n, fl), dtype=np.uint64)
+    for k in range(K):
+        if k == K - 1:  # z_mle: map_to_field of integers (zinc/prover.rs:299)
+            w = orc.splitmix64(seed + k, n)
+            for i in range(n):
+                out[k, i] = orc.int_to_limbs(orc.field_from_i64(f, int(w[i])), fl)
+        else:
+            vals = [int.from_bytes(rng.bytes(40), "little") % modulus for _ in range(n)]
+            out[k] = orc.field_elems(vals, fl)
+    return out
+
+
+@pytest.mark.parametrize("modulus,fl", [(BENCH_MODULUS, 4), (TEST_MODULUS_2, 2), (MOD_NO_SPARE, 4), (MOD_3LIMB, 3)])
+@pytest.mark.parametrize("K,degree,nv", [(2, 2, 10), (1, 1, 3), (3, 3, 7), (2, 3, 1), (4, 4, 5), (2, 2, 2)])
+def test_sumcheck_rounds_equal_the_oracle(mods, modulus, fl, K, degree, nv):
+    cabi, pcs = mods
+    f = orc.make_field(modulus, fl)
+    mles = _tables(f, fl, modulus, K, nv, seed=nv * 7 + K)
+    to = orc.new_transcript()
+    orc.absorb(to, b"sumcheck-2")
+    msgs_o, rand_o = orc.sumcheck_prove_product(f, mles, degree, to)
+    # through the host mirror (transcript on the host, rounds on the device)
+    t = pcs.KeccakTranscript()
+    t.absorb(b"sumcheck-2")
+    msgs, rand = pcs.sumcheck_prove_product(t, mles, degree, pcs.FieldConfig(modulus, fl))
+    assert np.array_equal(msgs, msgs_o)
+    assert np.array_equal(rand, rand_o)
+    assert t.get_u64() == orc.lib().orc_tr_get_u64(orc.C.byref(to))  # same Fiat-Shamir state afterwards
+
+
+def test_sumcheck_device_resident_tables_2pow20(mods):
+    """ZincProver's second sumcheck shape at 2^20 (CCS s = 20): two tables in HBM, read in place."""
+    torch = pytest.importorskip("torch")
+    cabi, pcs = mods
+    nv, fl, K, degree = 20, 4, 2, 2
+    f = orc.make_field(BENCH_MODULUS, fl)
+    rng = np.random.default_rng(5)
+    n = 1 << nv
+    # canonical residues below 2^250 < q, as raw Montgomery limbs
+    mles = rng.integers(0, 1 << 62, size=(K, n, fl), dtype=np.uint64)
+    mles[..., fl - 1] >>= np.uint64(6)
+    to = orc.new_transcript()
+    msgs_o, rand_o = orc.sumcheck_prove_product(f, mles, degree, to)
+    dev = [torch.from_numpy(mles[k].view(np.int64)).cuda() for k in range(K)]
+    before = [d.clone() for d in dev]
+    sc = cabi.Sumcheck(dev, nv, degree, cabi.make_field(BENCH_MODULUS, fl))
+    r = None
+    for i in range(nv):
+        ev = sc.round(r)
+        assert np.array_equal(ev, msgs_o[i]), i
+        r = rand_o[i]
+    with pytest.raises(cabi.ZipError):  # "Prover is not active" (prover.rs:91-93)
+        sc.round(r)
+    sc.free()
+    assert all(torch.equal(a, b) for a, b in zip(dev, before))  # the caller's tables were only read
+
+
+def test_sumcheck_usage_errors(mods):
+    cabi, pcs = mods
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    m = np.zeros((2, 8, 4), dtype=np.uint64)
+    with pytest.raises(cabi.ZipError):
+        cabi.Sumcheck(m, 0, 2, zf)        # "Attempt to prove a constant." (prover.rs:47-49)
+    with pytest.raises(cabi.ZipError):
+        cabi.Sumcheck(m, 3, 5, zf)        # degree beyond the supported 1..4
+    sc = cabi.Sumcheck(m, 3, 2, zf)
+    with pytest.raises(cabi.ZipError):
+        sc.round(np.ones(4, dtype=np.uint64))  # "first round should be prover first." (prover.rs:69-71)
+    sc.round()
+    with pytest.raises(cabi.ZipError):
+        sc.round()                         # "verifier message is empty" (prover.rs:87-89)

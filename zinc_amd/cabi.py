@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "zip_commitment_device_ptrs", "zip_commit_download", "zip_commitment_upload", "zip_open_testing",
     "zip_open_columns", "zip_open_eval", "zip_proof_len", "zip_open", "zip_sum_partials", "zip_merkle_trees",
     "zip_ctx_set_profiling", "zip_ctx_profile_read", "zip_verify", "zip_mle_eval", "zip_field_map_int256",
-    "zip_open_stream",
+    "zip_open_stream", "zip_sumcheck_init", "zip_sumcheck_round", "zip_sumcheck_last_error", "zip_sumcheck_free",
 )
 
 
@@ -109,6 +109,12 @@ def lib():
     L.zip_field_map_int256.argtypes = [vp, u64p, C.c_uint32, C.POINTER(ZipField), u64p]
     L.zip_open_stream.argtypes = [vp, i64p, C.c_int, i64p, u32p, C.c_uint32, u64p, C.POINTER(ZipField), PROOF_SINK,
                                   vp, C.c_size_t]
+    L.zip_sumcheck_init.argtypes = [C.c_int32, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ZipField), C.POINTER(vp)]
+    L.zip_sumcheck_round.argtypes = [vp, u64p, u64p]
+    L.zip_sumcheck_last_error.argtypes = [vp]
+    L.zip_sumcheck_last_error.restype = C.c_char_p
+    L.zip_sumcheck_free.argtypes = [vp]
+    L.zip_sumcheck_free.restype = None
     L.zip_commitment_free.argtypes = [vp]
     L.zip_commitment_free.restype = None
     L.zip_commitment_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
@@ -127,7 +133,7 @@ def lib():
     for fn in ("zip_ctx_create", "zip_ctx_synchronize", "zip_commit", "zip_commitment_device_ptrs",
                "zip_commit_download", "zip_commitment_upload", "zip_open_testing", "zip_open_columns",
                "zip_open_eval", "zip_open", "zip_sum_partials", "zip_merkle_trees", "zip_ctx_set_profiling",
-               "zip_ctx_profile_read", "zip_verify", "zip_mle_eval", "zip_field_map_int256", "zip_open_stream"):
+               "zip_ctx_profile_read", "zip_verify", "zip_mle_eval", "zip_field_map_int256", "zip_open_stream", "zip_sumcheck_init", "zip_sumcheck_round"):
         getattr(L, fn).restype = C.c_int32
     _lib = L
     return L
@@ -421,3 +427,44 @@ def merkle_trees(leaves, depth, device=0):
     if rc != ZIP_OK:
         raise ZipError(rc, "zip_merkle_trees")
     return out
+
+
+class Sumcheck:
+    """Device prover state of one product sumcheck (zip_sumcheck_*).  mles: list of CUDA int64/uint64 tensors
+    (read in place) or one numpy array [K, 2^nv, limbs] (copied)."""
+
+    def __init__(self, mles, num_vars, degree, field: ZipField, device=0):
+        self.field, self.degree = field, degree
+        if isinstance(mles, np.ndarray):
+            self._keep = np.ascontiguousarray(mles, dtype=np.uint64)
+            ptrs = [self._keep[k].ctypes.data for k in range(self._keep.shape[0])]
+            kind = MEM_HOST
+        else:
+            self._keep = list(mles)
+            ptrs = [t.data_ptr() for t in self._keep]
+            kind = MEM_DEVICE
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        h = C.c_void_p()
+        rc = lib().zip_sumcheck_init(device, arr, kind, len(ptrs), num_vars, degree, C.byref(field), C.byref(h))
+        if rc != ZIP_OK:
+            raise ZipError(rc, "zip_sumcheck_init", strerror(rc))
+        self._h = h
+
+    def round(self, r_prev=None):
+        out = np.zeros((self.degree + 1, self.field.limbs), dtype=np.uint64)
+        rp = None if r_prev is None else np.ascontiguousarray(r_prev, dtype=np.uint64)
+        rc = lib().zip_sumcheck_round(self._h, None if rp is None else rp.ctypes.data, out.ctypes.data)
+        if rc != ZIP_OK:
+            raise ZipError(rc, "zip_sumcheck_round", lib().zip_sumcheck_last_error(self._h).decode())
+        return out
+
+    def free(self):
+        if getattr(self, "_h", None):
+            lib().zip_sumcheck_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,188 @@
+// Sumcheck prover rounds for a product of multilinear extensions.
+//
+// Reference loops replaced:
+//   IPForMLSumcheck::prove_round          src/sumcheck/prover.rs:62-180  (comb_fn = product of the
+//                                         MLE values, ZincProver's second sumcheck, zinc/prover.rs:300)
+//   DenseMultilinearExtension::fix_variables  src/poly_f/mle/dense.rs:142-168
+//
+// One pass per round: the fold with the previous challenge (fix_variables) is fused into the
+// evaluation of the next round polynomial, so a round reads each table once and writes the half-size
+// folded tables (ping-pong buffers; the caller's tables are never written).  Everything is exact
+// field arithmetic on canonical Montgomery residues, so the per-thread / per-block partial sums
+// give the same evaluations as the reference's Rayon fold in any order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels_open.cuh"
+
+namespace zipk {
+
+constexpr int kSumcheckMaxMles = 4;
+constexpr int kSumcheckMaxDegree = 4;
+
+template <int FL>
+__device__ __forceinline__ void fe_add(uint64_t (&a)[FL], const uint64_t (&b)[FL], const FieldDev<FL> &f) {
+    const uint64_t c = add_n<FL>(a, b);
+    if (c || geq_n<FL>(a, f.modulus)) sub_n<FL>(a, f.modulus);
+}
+template <int FL>
+__device__ __forceinline__ void fe_sub(uint64_t (&a)[FL], const uint64_t (&b)[FL], const FieldDev<FL> &f) {
+    if (sub_n<FL>(a, b)) {  // a < b: add the modulus back (wraps when q has no spare bit; the sum is exact)
+        uint64_t q[FL];
+#pragma unroll
+        for (int i = 0; i < FL; i++) q[i] = f.modulus[i];
+        add_n<FL>(a, q);
+    }
+}
+template <int FL>
+__device__ __forceinline__ void fe_load(uint64_t (&a)[FL], const uint64_t *p) {
+#pragma unroll
+    for (int i = 0; i < FL; i++) a[i] = p[i];
+}
+template <int FL>
+__device__ __forceinline__ void fe_store(uint64_t *p, const uint64_t (&a)[FL]) {
+#pragma unroll
+    for (int i = 0; i < FL; i++) p[i] = a[i];
+}
+
+template <int FL>
+struct SumcheckRoundArgs {
+    const uint64_t *src[kSumcheckMaxMles];  // tables of this round's input (2*half entries, or 4*half when fold)
+    uint64_t *dst[kSumcheckMaxMles];        // folded tables (2*half entries) when fold
+    uint64_t r[FL];                         // previous round's challenge (Montgomery), when fold
+    uint32_t n_mles, degree, fold;
+    uint64_t half;                          // number of hypercube points b of this round: 2^(nv - round)
+    uint64_t *partials;                     // [gridDim.x][degree + 1][FL]
+};
+
+// DEG = degree of the round polynomial (evaluations at 0..DEG); a template parameter so that the
+// per-point accumulators live in registers.
+template <int FL, int DEG>
+__global__ void __launch_bounds__(256) sumcheck_round_kernel(SumcheckRoundArgs<FL> a, FieldDev<FL> f) {
+    extern __shared__ __align__(16) unsigned char sc_smem[];
+    uint64_t *red = reinterpret_cast<uint64_t *>(sc_smem);  // [256][DEG + 1][FL]
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t ne = DEG + 1;
+    uint64_t acc[DEG + 1][FL];
+#pragma unroll
+    for (int e = 0; e <= DEG; e++)
+#pragma unroll
+        for (int i = 0; i < FL; i++) acc[e][i] = 0;
+    uint64_t rr[FL];
+#pragma unroll
+    for (int i = 0; i < FL; i++) rr[i] = a.r[i];
+
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + tid; b < a.half; b += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t prod[DEG + 1][FL];
+#pragma unroll 1
+        for (uint32_t k = 0; k < a.n_mles; k++) {
+            uint64_t v0[FL], v1[FL];
+            if (a.fold) {  // fix_variables with the previous challenge: p'[j] = p[2j] + r (p[2j+1] - p[2j])
+                uint64_t l[FL], d[FL], t[FL];
+                const uint64_t *s = a.src[k] + (size_t)(4 * b) * FL;
+                fe_load<FL>(l, s);
+                fe_load<FL>(d, s + FL);
+                fe_sub<FL>(d, l, f);
+                mont_mul<FL>(d, rr, f, t);
+                fe_add<FL>(l, t, f);
+#pragma unroll
+                for (int i = 0; i < FL; i++) v0[i] = l[i];
+                fe_load<FL>(l, s + 2 * FL);
+                fe_load<FL>(d, s + 3 * FL);
+                fe_sub<FL>(d, l, f);
+                mont_mul<FL>(d, rr, f, t);
+                fe_add<FL>(l, t, f);
+#pragma unroll
+                for (int i = 0; i < FL; i++) v1[i] = l[i];
+                fe_store<FL>(a.dst[k] + (size_t)(2 * b) * FL, v0);
+                fe_store<FL>(a.dst[k] + (size_t)(2 * b + 1) * FL, v1);
+            } else {
+                const uint64_t *s = a.src[k] + (size_t)(2 * b) * FL;
+                fe_load<FL>(v0, s);
+                fe_load<FL>(v1, s + FL);
+            }
+            // the values of this MLE at t = 0, 1, 2, ..: v0, v1, v1 + step, .. (prover.rs:128-150)
+            uint64_t step[FL], val[FL];
+#pragma unroll
+            for (int i = 0; i < FL; i++) { step[i] = v1[i]; val[i] = v1[i]; }
+            fe_sub<FL>(step, v0, f);
+#pragma unroll
+            for (int e = 0; e <= DEG; e++) {
+                uint64_t cur[FL];
+                if (e == 0) {
+#pragma unroll
+                    for (int i = 0; i < FL; i++) cur[i] = v0[i];
+                } else {
+                    if (e >= 2) fe_add<FL>(val, step, f);
+#pragma unroll
+                    for (int i = 0; i < FL; i++) cur[i] = val[i];
+                }
+                if (k == 0) {
+#pragma unroll
+                    for (int i = 0; i < FL; i++) prod[e][i] = cur[i];
+                } else {
+                    uint64_t t[FL];
+                    mont_mul<FL>(prod[e], cur, f, t);
+#pragma unroll
+                    for (int i = 0; i < FL; i++) prod[e][i] = t[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e <= DEG; e++) fe_add<FL>(acc[e], prod[e], f);
+    }
+    // block sum
+#pragma unroll
+    for (int e = 0; e <= DEG; e++)
+#pragma unroll
+        for (int i = 0; i < FL; i++) red[((size_t)tid * ne + e) * FL + i] = acc[e][i];
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            for (uint32_t e = 0; e < ne; e++) {
+                uint64_t p[FL], q[FL];
+                fe_load<FL>(p, red + ((size_t)tid * ne + e) * FL);
+                fe_load<FL>(q, red + ((size_t)(tid + s) * ne + e) * FL);
+                fe_add<FL>(p, q, f);
+                fe_store<FL>(red + ((size_t)tid * ne + e) * FL, p);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < ne * FL) a.partials[(size_t)blockIdx.x * ne * FL + tid] = red[tid];
+}
+
+// evaluations[e] = sum over the blocks' partials (one workgroup; blocks <= a few thousand)
+template <int FL>
+__global__ void __launch_bounds__(256) sumcheck_reduce_kernel(const uint64_t *partials, uint32_t blocks, uint32_t ne,
+                                                              uint64_t *evaluations, FieldDev<FL> f) {
+    __shared__ uint64_t red[256 * FL];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t e = 0; e < ne; e++) {
+        uint64_t acc[FL];
+#pragma unroll
+        for (int i = 0; i < FL; i++) acc[i] = 0;
+        for (uint32_t b = tid; b < blocks; b += 256) {
+            uint64_t p[FL];
+            fe_load<FL>(p, partials + ((size_t)b * ne + e) * FL);
+            fe_add<FL>(acc, p, f);
+        }
+        fe_store<FL>(red + (size_t)tid * FL, acc);
+        __syncthreads();
+        for (uint32_t s = 128; s > 0; s >>= 1) {
+            if (tid < s) {
+                uint64_t p[FL], q[FL];
+                fe_load<FL>(p, red + (size_t)tid * FL);
+                fe_load<FL>(q, red + (size_t)(tid + s) * FL);
+                fe_add<FL>(p, q, f);
+                fe_store<FL>(red + (size_t)tid * FL, p);
+            }
+            __syncthreads();
+        }
+        if (tid < FL) evaluations[(size_t)e * FL + tid] = red[tid];
+        __syncthreads();
+    }
+}
+
+}  // namespace zipk

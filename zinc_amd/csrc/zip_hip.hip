@@ -21,6 +21,7 @@
 #include "kernels_commit.cuh"
 #include "kernels_open.cuh"
 #include "kernels_verify.cuh"
+#include "kernels_sumcheck.cuh"
 
 using namespace zipk;
 
@@ -96,6 +97,18 @@ struct zip_commitment {
     hipEvent_t zeroed = nullptr;     // counters reset (consumers must not look at stale values)
     hipEvent_t done = nullptr;       // whole commit finished
     std::vector<hipEvent_t> aux;     // other events owned by the handle, recycled with it
+};
+
+// Prover state of one sumcheck (ProverState, src/sumcheck/prover.rs:25-37) on the device.
+struct zip_sumcheck {
+    zip_ctx *ctx = nullptr;  // private plumbing context (stream, pool, error text)
+    uint32_t n_mles = 0, num_vars = 0, degree = 0, fl = 0, round = 0;
+    const uint64_t *input[4] = {};  // the tables of round 1 (device; owned when `owned`)
+    bool owned = false;
+    uint64_t *buf[2][4] = {};       // ping-pong fold targets: 2^(nv-1) and 2^(nv-2) entries
+    uint64_t *partials = nullptr, *evals_d = nullptr;
+    uint32_t max_blocks = 0;
+    uint64_t modulus[8] = {};
 };
 
 namespace {
@@ -870,6 +883,55 @@ int32_t run_verify_fl(zip_ctx *ctx, const VerifyIn &in, const HostField &hf, std
     return ZIP_OK;
 }
 
+}  // namespace
+
+// ---- sumcheck prover -----------------------------------------
+namespace {
+template <int FL, int DEG>
+int32_t launch_sumcheck_round(zip_sumcheck *s, const SumcheckRoundArgs<FL> &a, uint32_t blocks, const FieldDev<FL> &fd) {
+    zip_ctx *ctx = s->ctx;
+    const size_t lds = (size_t)256 * (DEG + 1) * FL * 8;
+    {
+        LaunchTimer t(ctx, "sumcheck_round_kernel");
+        hipLaunchKernelGGL((sumcheck_round_kernel<FL, DEG>), dim3(blocks), dim3(256), lds, ctx->stream, a, fd);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    {
+        LaunchTimer t(ctx, "sumcheck_reduce_kernel");
+        hipLaunchKernelGGL(sumcheck_reduce_kernel<FL>, dim3(1), dim3(256), 0, ctx->stream, a.partials, blocks, (uint32_t)(DEG + 1),
+                           s->evals_d, fd);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return ZIP_OK;
+}
+
+template <int FL>
+int32_t sumcheck_round_fl(zip_sumcheck *s, const uint64_t *r_prev, const HostField &hf) {
+    SumcheckRoundArgs<FL> a{};
+    const uint32_t round = s->round + 1;  // 1-based
+    a.n_mles = s->n_mles;
+    a.degree = s->degree;
+    a.half = (uint64_t)1 << (s->num_vars - round);
+    a.fold = round > 1;
+    a.partials = s->partials;
+    for (uint32_t k = 0; k < s->n_mles; k++) {
+        // round 1 reads the input; round 2 folds input -> buf[0]; round j >= 3 folds buf[j & 1] ... alternating
+        if (round == 1) a.src[k] = s->input[k];
+        else if (round == 2) { a.src[k] = s->input[k]; a.dst[k] = s->buf[0][k]; }
+        else { a.src[k] = s->buf[(round - 3) & 1][k]; a.dst[k] = s->buf[(round - 2) & 1][k]; }
+    }
+    if (a.fold)
+        for (int i = 0; i < FL; i++) a.r[i] = r_prev[i];
+    uint64_t want = (a.half + 255) / 256;
+    uint32_t blocks = (uint32_t)std::min<uint64_t>(want ? want : 1, s->max_blocks);
+    const FieldDev<FL> fd = to_dev<FL>(hf);
+    switch (s->degree) {
+        case 1: return launch_sumcheck_round<FL, 1>(s, a, blocks, fd);
+        case 2: return launch_sumcheck_round<FL, 2>(s, a, blocks, fd);
+        case 3: return launch_sumcheck_round<FL, 3>(s, a, blocks, fd);
+        default: return launch_sumcheck_round<FL, 4>(s, a, blocks, fd);
+    }
+}
 }  // namespace
 
 // =============================================================================
@@ -1662,6 +1724,102 @@ int32_t zip_open_stream(zip_commitment *c, const int64_t *evals, zip_mem_kind ev
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (sink(user, ctx->bounce[0], row_bytes)) return fail(ctx, ZIP_ERR_INVALID_PARAM, "the proof sink refused the stream");
     return check_timeout(ctx);
+}
+
+int32_t zip_sumcheck_init(int32_t device, const uint64_t *const *mles, zip_mem_kind kind, uint32_t n_mles,
+                          uint32_t num_vars, uint32_t degree, const zip_field *field, zip_sumcheck **out) {
+    if (!mles || !out || !field) return ZIP_ERR_NULL;
+    *out = nullptr;
+    if (n_mles < 1 || n_mles > (uint32_t)kSumcheckMaxMles || degree < 1 || degree > (uint32_t)kSumcheckMaxDegree ||
+        num_vars < 1 || num_vars > 30)
+        return ZIP_ERR_INVALID_PARAM;  // nvars == 0: "Attempt to prove a constant." (prover.rs:47-49)
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return ZIP_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return ZIP_ERR_NO_DEVICE;
+    zip_ctx *ctx = new (std::nothrow) zip_ctx();
+    zip_sumcheck *s = new (std::nothrow) zip_sumcheck();
+    if (!ctx || !s) { delete ctx; delete s; return ZIP_ERR_ALLOC; }
+    ctx->device = device;
+    s->ctx = ctx;
+    int32_t rc = ZIP_OK;
+    do {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
+        HostField hf;
+        if ((rc = make_field(ctx, field, &hf))) break;
+        s->n_mles = n_mles;
+        s->num_vars = num_vars;
+        s->degree = degree;
+        s->fl = hf.fl;
+        memcpy(s->modulus, hf.modulus, sizeof s->modulus);
+        const size_t n = (size_t)1 << num_vars, elem = (size_t)hf.fl * 8;
+        for (uint32_t k = 0; k < n_mles && rc == ZIP_OK; k++) {
+            if (!mles[k]) { rc = ZIP_ERR_NULL; break; }
+            if (kind == ZIP_MEM_HOST) {
+                void *d = nullptr;
+                if ((rc = pool_alloc(ctx, n * elem, &d))) break;
+                s->input[k] = static_cast<uint64_t *>(d);
+                rc = copy_h2d_bounced(ctx, d, mles[k], n * elem, ctx->stream);
+            } else {
+                s->input[k] = mles[k];
+            }
+            if (rc) break;
+            if (num_vars >= 2 && (rc = pool_alloc(ctx, (n / 2) * elem, (void **)&s->buf[0][k]))) break;
+            if (num_vars >= 3 && (rc = pool_alloc(ctx, (n / 4) * elem, (void **)&s->buf[1][k]))) break;
+        }
+        if (rc) break;
+        s->owned = kind == ZIP_MEM_HOST;
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        s->max_blocks = (uint32_t)cus * 8;
+        if ((rc = pool_alloc(ctx, (size_t)s->max_blocks * (degree + 1) * elem, (void **)&s->partials))) break;
+        if ((rc = pool_alloc(ctx, (size_t)(degree + 1) * elem, (void **)&s->evals_d))) break;
+    } while (0);
+    if (rc) {
+        zip_sumcheck_free(s);
+        return rc;
+    }
+    *out = s;
+    return ZIP_OK;
+}
+
+int32_t zip_sumcheck_round(zip_sumcheck *s, const uint64_t *r_prev, uint64_t *evaluations_out) {
+    if (!s || !evaluations_out) return ZIP_ERR_NULL;
+    zip_ctx *ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (s->round >= s->num_vars) return fail(ctx, ZIP_ERR_INVALID_PARAM, "Prover is not active");  // prover.rs:91-93
+    if (s->round == 0 && r_prev) return fail(ctx, ZIP_ERR_INVALID_PARAM, "first round should be prover first.");
+    if (s->round > 0 && !r_prev) return fail(ctx, ZIP_ERR_INVALID_PARAM, "verifier message is empty");
+    HostField hf;
+    zip_field zf{};
+    zf.limbs = s->fl;
+    memcpy(zf.modulus, s->modulus, sizeof zf.modulus);
+    int32_t rc;
+    if ((rc = make_field(ctx, &zf, &hf))) return rc;
+    switch (s->fl) {
+        case 2: rc = sumcheck_round_fl<2>(s, r_prev, hf); break;
+        case 3: rc = sumcheck_round_fl<3>(s, r_prev, hf); break;
+        default: rc = sumcheck_round_fl<4>(s, r_prev, hf); break;
+    }
+    if (rc) return rc;
+    s->round++;
+    HIP_TRY(ctx, hipMemcpyAsync(evaluations_out, s->evals_d, (size_t)(s->degree + 1) * s->fl * 8, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ZIP_OK;
+}
+
+const char *zip_sumcheck_last_error(const zip_sumcheck *s) { return s && s->ctx ? s->ctx->last_error.c_str() : ""; }
+
+void zip_sumcheck_free(zip_sumcheck *s) {
+    if (!s) return;
+    if (s->ctx) {
+        if (!s->owned) {  // the caller's tables are not ours to free
+            std::lock_guard<std::mutex> g(s->ctx->mu);
+            for (auto *p : s->input) s->ctx->live_blocks.erase(const_cast<uint64_t *>(p));
+        }
+        zip_ctx_destroy(s->ctx);  // frees every pool block, the stream, the events
+    }
+    delete s;
 }
 
 int32_t zip_sum_partials(zip_ctx *ctx, const uint64_t *uparts, const uint64_t *fparts, uint32_t n_parts,

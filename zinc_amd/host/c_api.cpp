@@ -244,4 +244,21 @@ void zinc_zip_proof_read(const zinc_zip_proof *p, uint8_t *roots_out, uint64_t *
 }
 void zinc_zip_proof_free(zinc_zip_proof *p) { delete p; }
 
+int32_t zinc_sumcheck_prove_product(zinc_transcript *transcript, const uint64_t *const *mles, uint32_t n_mles,
+                                    uint32_t nvars, uint32_t degree, const uint64_t *modulus, uint32_t limbs,
+                                    int32_t device, uint64_t *msgs_out, uint64_t *randomness_out) {
+    if (!transcript || !mles || !msgs_out || !randomness_out) return ZINC_ERR_NULL;
+    return guarded([&] {
+        const FieldConfig f = FieldConfig::make(modulus, limbs);
+        std::vector<const uint64_t *> tables(mles, mles + n_mles);
+        const auto res = zinc::sumcheck::prove_as_subprotocol_product(transcript->t, tables, nvars, degree, f, device);
+        for (size_t r = 0; r < res.proof.msgs.size(); r++) {
+            for (uint32_t e = 0; e <= degree; e++)
+                for (uint32_t i = 0; i < limbs; i++)
+                    msgs_out[(r * (degree + 1) + e) * limbs + i] = res.proof.msgs[r][e][i];
+            for (uint32_t i = 0; i < limbs; i++) randomness_out[r * limbs + i] = res.randomness[r][i];
+        }
+    });
+}
+
 }  // extern "C"

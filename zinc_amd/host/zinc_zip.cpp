@@ -788,4 +788,36 @@ zip::ZipProof zip::commit_z_mle_and_prove_evaluation(const LinearCodeSpec &lc_sp
     return out;
 }
 
+sumcheck::ProverOutput sumcheck::prove_as_subprotocol_product(KeccakTranscript &transcript,
+                                                              const std::vector<const uint64_t *> &mles, uint32_t nvars,
+                                                              uint32_t degree, const FieldConfig &config, int device) {
+    // sumcheck.rs:64-76 (FIELD_LIMBS > 1: the u128 map)
+    transcript.absorb_random_field(config, map_to_field_u128(config, nvars, 0));
+    transcript.absorb_random_field(config, map_to_field_u128(config, degree, 0));
+    ProverOutput out;
+    if (nvars == 0) return out;  // :77-92: empty proof
+    const zip_field zf = config.to_abi();
+    zip_sumcheck *raw = nullptr;
+    int32_t rc = zip_sumcheck_init(device, mles.data(), ZIP_MEM_HOST, (uint32_t)mles.size(), nvars, degree, &zf, &raw);
+    if (rc) throw ZipError(rc == ZIP_ERR_INVALID_PARAM ? ZipError::InvalidPcsParam : ZipError::Device,
+                           std::string("zip_sumcheck_init: ") + zip_strerror(rc));
+    std::unique_ptr<zip_sumcheck, void (*)(zip_sumcheck *)> s(raw, zip_sumcheck_free);
+    std::vector<uint64_t> evals((size_t)(degree + 1) * config.limbs);
+    Limbs r{};
+    for (uint32_t round = 0; round < nvars; round++) {  // :97-106
+        rc = zip_sumcheck_round(s.get(), round ? r.data() : nullptr, evals.data());
+        if (rc) throw ZipError(ZipError::Device, std::string("zip_sumcheck_round: ") + zip_sumcheck_last_error(s.get()));
+        std::vector<Limbs> msg(degree + 1);
+        for (uint32_t e = 0; e <= degree; e++) {
+            for (uint32_t i = 0; i < config.limbs; i++) msg[e][i] = evals[(size_t)e * config.limbs + i];
+            transcript.absorb_random_field(config, msg[e]);  // absorb_slice
+        }
+        out.proof.msgs.push_back(std::move(msg));
+        r = transcript.get_challenge(config);   // sample_round
+        transcript.absorb_random_field(config, r);
+        out.randomness.push_back(r);
+    }
+    return out;
+}
+
 }  // namespace zinc

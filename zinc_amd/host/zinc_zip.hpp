@@ -245,4 +245,21 @@ ZipProof commit_z_mle_and_prove_evaluation(const LinearCodeSpec &lc_spec, const 
                                            const FieldConfig &config, int device = 0);
 
 }  // namespace zip
+
+// ---------------------------------------------------------------------------- sumcheck
+// MLSumcheck::prove_as_subprotocol (src/sumcheck.rs:56-112) for comb_fn = product of the MLE values
+// (ZincProver::sumcheck_2, src/zinc/prover.rs:297-302): the rounds run on the device
+// (zip_sumcheck_round), the transcript stays here.
+namespace sumcheck {
+struct SumcheckProof {                       // SumcheckProof(Vec<ProverMsg>) (src/sumcheck.rs:24-26)
+    std::vector<std::vector<Limbs>> msgs;    // per round: evaluations at 0..degree
+};
+struct ProverOutput {
+    SumcheckProof proof;
+    std::vector<Limbs> randomness;           // ProverState.randomness
+};
+// mles[k]: 2^nvars field elements as flat little-endian Montgomery limbs (config.limbs each), host memory.
+ProverOutput prove_as_subprotocol_product(KeccakTranscript &transcript, const std::vector<const uint64_t *> &mles,
+                                          uint32_t nvars, uint32_t degree, const FieldConfig &config, int device = 0);
+}  // namespace sumcheck
 }  // namespace zinc

@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "zinc_pcs_transcript_free", "zinc_pcs_transcript_len", "zinc_pcs_transcript_copy",
     "zinc_pcs_transcript_probe", "zinc_zip_open", "zinc_pcs_transcript_from_proof", "zinc_pcs_transcript_position",
     "zinc_zip_verify", "zinc_zip_evaluate", "zinc_commit_z_mle_and_prove_evaluation", "zinc_zip_proof_len",
-    "zinc_zip_proof_num_roots", "zinc_zip_proof_read", "zinc_zip_proof_free", "zinc_zip_release_cached_contexts",
+    "zinc_zip_proof_num_roots", "zinc_zip_proof_read", "zinc_zip_proof_free", "zinc_zip_release_cached_contexts", "zinc_sumcheck_prove_product",
 )
 
 
@@ -100,6 +100,7 @@ def lib():
         L.zinc_zip_proof_read.argtypes = [vp, vp, vp, vp]
         L.zinc_zip_proof_read.restype = None
         L.zinc_zip_proof_free.argtypes = [vp]
+        L.zinc_sumcheck_prove_product.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_int32, vp, vp]
         _lib = L
     return _lib
 
@@ -314,3 +315,17 @@ def commit_z_mle_and_prove_evaluation(z_evals, r_y: np.ndarray, transcript: Kecc
     finally:
         lib().zinc_zip_proof_free(h)
     return roots, v, proof
+
+
+def sumcheck_prove_product(transcript: KeccakTranscript, mles, degree: int, field: FieldConfig, device: int = 0):
+    """MLSumcheck::prove_as_subprotocol for comb_fn = product of the MLEs (src/sumcheck.rs:56-112).
+    mles: [K, 2^nv, limbs] Montgomery limbs.  Returns (msgs [nv, degree+1, limbs], randomness [nv, limbs])."""
+    m = np.ascontiguousarray(mles, dtype=np.uint64)
+    K, n, fl = m.shape
+    nv = n.bit_length() - 1
+    ptrs = (C.c_void_p * K)(*[m[k].ctypes.data for k in range(K)])
+    msgs = np.zeros((nv, degree + 1, fl), np.uint64)
+    rand = np.zeros((nv, fl), np.uint64)
+    _check(lib().zinc_sumcheck_prove_product(transcript._h, ptrs, K, nv, degree, field._m.ctypes.data, fl, device,
+                                             msgs.ctypes.data, rand.ctypes.data))
+    return msgs, rand
