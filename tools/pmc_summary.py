@@ -37,6 +37,7 @@ def pmc(d, counter):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trace"), ap.add_argument("--fetch"), ap.add_argument("--write")
+    ap.add_argument("--sq"), ap.add_argument("--verify"), ap.add_argument("--sumcheck")
     ap.add_argument("--tag", default="round1")
     ap.add_argument("--num-vars", type=int, default=24)
     a = ap.parse_args()
@@ -46,6 +47,10 @@ def main():
         st = find(a.trace, "*kernel_stats.csv")
         if st:
             shutil.copy(st, os.path.join(prof, f"{a.tag}_kernel_stats.csv"))
+    for d, name in ((a.verify, "verify"), (a.sumcheck, "sumcheck")):
+        st = find(d, "*kernel_stats.csv") if d else None
+        if st:
+            shutil.copy(st, os.path.join(prof, f"{a.tag}_{name}_kernel_stats.csv"))
     fetch, write = pmc(a.fetch, "FETCH_SIZE") if a.fetch else {}, pmc(a.write, "WRITE_SIZE") if a.write else {}
     lines = [f"# {a.tag}: HBM traffic per launch from rocprofv3 --pmc (separate passes)", "",
              "FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide",
@@ -66,6 +71,18 @@ def main():
             traffic[short] = {"num_vars": a.num_vars, "fetch_kib": fk, "write_kib": wk,
                               "traffic_bytes": b2 if short == "raa_commit_kernel" else b1,
                               "source": f"profiles/{a.tag}_pmc.md"}
+    if a.sq:
+        # VALU utilisation of each kernel: issued VALU wave-instructions (one per 4 SIMD cycles) against the
+        # SIMD cycles of its launch, SQ_BUSY_CYCLES being per shader engine x 4 SIMDs ... the ratio that is
+        # unit-free is SQ_ACTIVE_INST_VALU (quad-cycles a VALU instruction was executing) / SQ_WAVE_CYCLES
+        # (quad-cycles waves were resident) x waves per SIMD; both are listed as collected.
+        sq = {c: pmc(a.sq, c) for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU")}
+        lines += ["", "## SQ counters per launch (one pass)", "",
+                  "| kernel | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU | SQ_WAVE_CYCLES | SQ_BUSY_CYCLES |", "|---|---|---|---|---|"]
+        for k in sorted(set().union(*[set(v) for v in sq.values()])):
+            avg = lambda c: sum(sq[c].get(k, [0])) / max(len(sq[c].get(k, [])), 1)
+            lines.append(f"| `{k[:70]}` | {avg('SQ_INSTS_VALU'):,.0f} | {avg('SQ_ACTIVE_INST_VALU'):,.0f} | "
+                         f"{avg('SQ_WAVE_CYCLES'):,.0f} | {avg('SQ_BUSY_CYCLES'):,.0f} |")
     with open(os.path.join(prof, f"{a.tag}_pmc.md"), "w") as fh:
         fh.write("\n".join(lines) + "\n")
     if traffic:
