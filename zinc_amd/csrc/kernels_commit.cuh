@@ -59,21 +59,49 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// One DPP move of a 96-bit value: lanes without a source lane (or outside row_mask) read 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ i128 dpp_i96(i128 x) {
+    const int d0 = (int)(uint32_t)x, d1 = (int)(uint32_t)((u128)x >> 32), d2 = (int)(uint32_t)((u128)x >> 64);
+    const uint32_t y0 = (uint32_t)__builtin_amdgcn_update_dpp(0, d0, CTRL, ROW_MASK, 0xF, false);
+    const uint32_t y1 = (uint32_t)__builtin_amdgcn_update_dpp(0, d1, CTRL, ROW_MASK, 0xF, false);
+    const uint32_t y2 = (uint32_t)__builtin_amdgcn_update_dpp(0, d2, CTRL, ROW_MASK, 0xF, false);
+    const int64_t hi = (int64_t)(int32_t)y2;  // sign-extend bit 95
+    return (i128)(((u128)(uint64_t)hi << 64) | ((u128)y1 << 32) | y0);
+}
+
 // Exclusive prefix over the workgroup of one (<= 96-bit signed) value per thread.
-// wave_tot: LDS scratch of >= 16 entries.  Contains two (LDS-only) barriers.
-__device__ __forceinline__ i128 block_exclusive_scan_i96(i128 total, i128 *wave_tot) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+// wave_tot: LDS scratch of 2 x 16 entries; `which` (0/1) selects the half, and consecutive calls must
+// alternate so that ONE (LDS-only) barrier per call suffices: a half is rewritten only two calls later.
+// Both levels are DPP scans (row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast:15 / :31 across
+// them): VALU-rate data movement instead of dependent ds_bpermute round trips and a serial loop over
+// the wave totals, on the critical path between the barriers of every row.
+__device__ __forceinline__ i128 block_exclusive_scan_i96(i128 total, i128 *wave_tot, int which) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     i128 x = total;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        i128 y = shfl_up_i96(x, off);
-        if (lane >= off) x += y;
-    }
-    if (lane == 63) wave_tot[wid] = x;
+    x += dpp_i96<0x111, 0xF>(x);  // row_shr:1
+    x += dpp_i96<0x112, 0xF>(x);  // row_shr:2
+    x += dpp_i96<0x114, 0xF>(x);  // row_shr:4
+    x += dpp_i96<0x118, 0xF>(x);  // row_shr:8
+    x += dpp_i96<0x142, 0xA>(x);  // row_bcast:15 -> rows 1, 3
+    x += dpp_i96<0x143, 0xC>(x);  // row_bcast:31 -> rows 2, 3
+    i128 *tot = wave_tot + 16 * which;
+    if (lane == 63) tot[wid] = x;
     lds_barrier();
+    // every wave scans the (<= 16) wave totals in its first row of lanes and picks its predecessor's
+    i128 t = lane < 16 ? tot[lane] : (i128)0;
+    t += dpp_i96<0x111, 0xF>(t);
+    t += dpp_i96<0x112, 0xF>(t);
+    t += dpp_i96<0x114, 0xF>(t);
+    t += dpp_i96<0x118, 0xF>(t);
     i128 base = 0;
-    for (int w = 0; w < wid; w++) base += wave_tot[w];
-    lds_barrier();
+    if (wid > 0) {
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)t, wid - 1);
+        const uint32_t b1 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((u128)t >> 32), wid - 1);
+        const uint32_t b2 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((u128)t >> 64), wid - 1);
+        base = (i128)(((u128)(uint64_t)(int64_t)(int32_t)b2 << 64) | ((u128)b1 << 32) | b0);
+    }
     return base + (x - total);
 }
 
@@ -236,8 +264,8 @@ __global__ void __launch_bounds__(1024, (E <= 8 ? 5 : 4)) raa_commit_kernel(Comm
     const uint32_t cw = a.cw, row_len = a.row_len;
     const bool active = tid0 < a.nact;
 
-    i128 *wave_tot = reinterpret_cast<i128 *>(smem);                  // 16 entries
-    uint64_t *t2lo = reinterpret_cast<uint64_t *>(smem + 256);         // E planes of PS slots
+    i128 *wave_tot = reinterpret_cast<i128 *>(smem);                  // 2 x 16 entries
+    uint64_t *t2lo = reinterpret_cast<uint64_t *>(smem + 512);         // E planes of PS slots
     uint32_t *t2hi = reinterpret_cast<uint32_t *>(t2lo + (T2_LDS ? E * PS : 0));
     int64_t *rowbuf = reinterpret_cast<int64_t *>(t2hi + (T2_LDS ? E * PS : 0));
 
@@ -304,7 +332,7 @@ __global__ void __launch_bounds__(1024, (E <= 8 ? 5 : 4)) raa_commit_kernel(Comm
             for (int e = 0; e < E; e++) v[e] = 0;
         }
         {
-            const i128 pre = block_exclusive_scan_i96(v[E - 1], wave_tot);
+            const i128 pre = block_exclusive_scan_i96(v[E - 1], wave_tot, 0);
             if (active) {
 #pragma unroll
                 for (int e = 0; e < E; e++) {
@@ -338,7 +366,7 @@ __global__ void __launch_bounds__(1024, (E <= 8 ? 5 : 4)) raa_commit_kernel(Comm
         }
         {
             // the barriers inside also order the t2 reads above before the stores below
-            const i128 pre = block_exclusive_scan_i96(v[E - 1], wave_tot);
+            const i128 pre = block_exclusive_scan_i96(v[E - 1], wave_tot, 1);
 #pragma unroll
             for (int e = 0; e < E; e++) v[e] += pre;
         }

@@ -448,7 +448,7 @@ FieldDev<FL> to_dev(const HostField &h) {
 template <int E, bool HASH, bool T2_LDS>
 int32_t launch_commit(zip_ctx *ctx, const CommitArgs &a, uint32_t threads, uint32_t grid, hipStream_t st) {
     // wave totals + E planes of (threads + 32/E) slots of 12 bytes + the witness row
-    const size_t lds = 256 + (T2_LDS ? (size_t)E * (threads + 32 / E) * 12 + (size_t)a.row_len * 8 : 0);
+    const size_t lds = 512 + (T2_LDS ? (size_t)E * (threads + 32 / E) * 12 + (size_t)a.row_len * 8 : 0);
     auto kern = raa_commit_kernel<E, HASH, T2_LDS>;
     static size_t lds_attr = 0;  // per instantiation
     if (lds > lds_attr) {
@@ -474,7 +474,7 @@ CommitGeom commit_geom(uint32_t cw, uint32_t row_len) {
     else if (cw == 256) { g.e = 4; g.threads = 64; g.levels_done = 2; g.t2_lds = true; }
     else if (cw == 128) { g.e = 2; g.threads = 64; g.levels_done = 1; g.t2_lds = true; }
     else { g.e = 1; g.threads = 64; g.levels_done = 0; g.t2_lds = true; }  // cw <= 64: one entry per lane
-    g.lds = 256 + (g.t2_lds ? (size_t)g.e * (g.threads + 32 / g.e) * 12 + (size_t)row_len * 8 : 0);
+    g.lds = 512 + (g.t2_lds ? (size_t)g.e * (g.threads + 32 / g.e) * 12 + (size_t)row_len * 8 : 0);
     return g;
 }
 // resident workgroups per CU of the commit kernel (threads and LDS)
