@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--num-vars", type=int, default=24)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--serial", action="store_true", help="wait for the commit before opening (kernels timed alone)")
     args = ap.parse_args()
     import torch
 
@@ -31,6 +32,8 @@ def main():
         if rep == 1:
             ctx.set_profiling(True)
         com, _ = ctx.commit(evals, want_roots=False)
+        if args.serial:
+            ctx.synchronize()
         com.open(evals, coeffs, cols, q0, zf, out=proof)
         com.free()
         c2, _ = ctx.commit(evals, with_merkle=False)
