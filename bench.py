@@ -143,14 +143,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal knobs (not used by the driver): BENCH_BACKEND=gloo with BENCH_DEVICE=0 runs the multi-rank
+    # control flow with every rank on one GPU, the exchanges staged through host tensors.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if "BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["BENCH_DEVICE"])
     dist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = dev if backend == "nccl" else torch.device("cpu")  # where collectives operate
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
 
     from zinc_amd import cabi
     from zinc_amd.perm import shuffle_seeded_perm
@@ -181,7 +190,7 @@ def main():
     evals_d = torch.from_numpy(np.ascontiguousarray(witness)).to(dev)
     if not rows_mode:
         proof = torch.empty(ctx.proof_len(n_cols, fl), dtype=torch.uint8, device=dev)
-        roots_all = torch.empty((world * per, 32), dtype=torch.uint8, device=dev) if world > 1 else None
+        roots_all = torch.empty((world * per, 32), dtype=torch.uint8, device=xdev) if world > 1 else None
 
     def step():
         if rows_mode:
@@ -191,8 +200,11 @@ def main():
             com, _ = ctx.commit(evals_d, want_roots=False)  # asynchronous: the open below overlaps it
             com.open(evals_d, coeffs, cols, q0, zf, out=proof)  # returns when the whole stream is in HBM
             if world > 1:
+                # the one exchange of the commit: every rank's Merkle roots
                 _, _, roots_ptr = com.device_ptrs()
-                dist.all_gather_into_tensor(roots_all, roots_view(torch, roots_ptr, per, dev))
+                mine = roots_view(torch, roots_ptr, per, dev)
+                dist.all_gather_into_tensor(roots_all, mine if backend == "nccl" else mine.cpu())
+                torch.cuda.current_stream().synchronize()  # the roots buffer returns to the pool below
         com.free()
 
     def barrier():
@@ -213,7 +225,7 @@ def main():
     ktimes = ctx.profile_read()
     ctx.set_profiling(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
