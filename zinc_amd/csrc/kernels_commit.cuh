@@ -167,9 +167,10 @@ struct StridedLeaves {
     uint64_t *out_row;
     uint32_t *tree;
     uint32_t cw, T, tid;
+    uint32_t base = 0;  // first entry of the strip the butterfly covers (a multiple of E * T)
     template <int E0>
     __device__ __forceinline__ void store_row() {
-        const uint32_t j = E0 * T + tid;
+        const uint32_t j = base + E0 * T + tid;
         const uint32_t s = (uint32_t)((int32_t)w2[E0] >> 31);
         uint4 *o = reinterpret_cast<uint4 *>(out_row + (size_t)j * 4);
         o[0] = make_uint4(w0[E0], w1[E0], w2[E0], s);  // sign extension to Int<4>
@@ -179,13 +180,13 @@ struct StridedLeaves {
     __device__ __forceinline__ void leaf(uint32_t (&h)[8]) {
         store_row<E0>();
         blake3_leaf_sext96(w0[E0], w1[E0], w2[E0], h);
-        store_hash(tree + (size_t)(E0 * T + tid) * 8, h);
+        store_hash(tree + (size_t)(base + E0 * T + tid) * 8, h);
     }
     // node of local level LVL computed by this lane: step E0 + (tid mod 2^LVL)
     template <int LVL, int E0>
     __device__ __forceinline__ void store(const uint32_t (&h)[8]) {
         const uint32_t e = E0 + (tid & ((1u << LVL) - 1u));
-        store_hash(tree + ((size_t)level_off(cw, LVL) + ((e * T + tid) >> LVL)) * 8, h);
+        store_hash(tree + ((size_t)level_off(cw, LVL) + ((base + e * T + tid) >> LVL)) * 8, h);
     }
 };
 
@@ -215,6 +216,61 @@ __device__ __forceinline__ void bfly_hash(Src &src, uint32_t (&h)[8]) {
         }
         blake3_block(m, 64u, h);
         src.template store<LVL, E0>(h);
+    }
+}
+
+// End of a chunk of rows of one workgroup of a persistent commit kernel: the tree levels
+// `first_level` .. depth of the rows it encoded in the chunk, level by level over all of them at once
+// (the first levels keep every lane busy, and the serial tail -- one node per row at the top -- is
+// paid once per chunk, not per row), the roots, then the publication of the chunk.  The children of
+// the first level were stored by this workgroup: a barrier makes them visible (one CU, one L1; the
+// lines were never read before they were written).
+template <bool HASH>
+__device__ __forceinline__ void finish_chunk(const CommitArgs &a, uint32_t first_level, uint32_t round, uint32_t tid,
+                                             uint32_t T) {
+    const uint32_t cw = a.cw;
+    if (HASH) {
+        const uint32_t first = (round / a.rounds_per_chunk) * a.rounds_per_chunk;
+        const uint32_t nrows_c = round - first + 1;
+        const uint32_t depth = 31u - __builtin_clz(cw);
+        __syncthreads();
+        for (uint32_t lvl = first_level; lvl <= depth; lvl++) {
+            const uint32_t wshift = depth - lvl;  // log2(width of this level)
+            const uint32_t total = nrows_c << wshift;
+            for (uint32_t idx = tid; idx < total; idx += T) {
+                const uint32_t ri = idx >> wshift, i = idx & ((1u << wshift) - 1u);
+                const uint32_t r = blockIdx.x + (first + ri) * gridDim.x;
+                uint32_t *tree = a.layers + (size_t)r * (2u * cw) * 8;
+                const uint32_t *ch = tree + ((size_t)level_off(cw, lvl - 1) + 2u * i) * 8;
+                uint32_t l[8], rr[8], h[8];
+                load_hash(ch, l);
+                load_hash(ch + 8, rr);
+                blake3_node(l, rr, h);
+                store_hash(tree + ((size_t)level_off(cw, lvl) + i) * 8, h);
+                if (lvl == depth) store_hash(a.roots + (size_t)r * 8, h);
+            }
+            __syncthreads();
+        }
+        if (depth == 0 && tid == 0) {  // a one-leaf tree: the root is the leaf hash
+            for (uint32_t ri = 0; ri < nrows_c; ri++) {
+                const uint32_t r = blockIdx.x + (first + ri) * gridDim.x;
+                uint32_t h[8];
+                load_hash(a.layers + (size_t)r * (2u * cw) * 8, h);
+                store_hash(a.roots + (size_t)r * 8, h);
+            }
+        }
+    }
+    if (a.chunk_done) {
+        __syncthreads();  // every wave's stores are issued and waited for (vmcnt(0) + barrier)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back has landed before the count moves
+            __hip_atomic_fetch_add(&a.chunk_done[round / a.rounds_per_chunk], 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+#ifdef ZIPK_DEBUG_STAMPS
+            a.stamps[(round / a.rounds_per_chunk) * gridDim.x + blockIdx.x] = wall_clock64();
+#endif
+        }
     }
 }
 
@@ -435,54 +491,7 @@ __global__ void __launch_bounds__(1024, (E <= 8 ? 5 : 4)) raa_commit_kernel(Comm
         // ---- finish a chunk: upper Merkle levels of this workgroup's rows, then publish ------
         const bool last = row + gridDim.x >= a.num_rows;
         if (last || (round + 1) % a.rounds_per_chunk == 0) {
-            if (HASH) {
-                // Levels LOGE+1 .. depth of the rows this workgroup encoded in the chunk, level by
-                // level over all of them at once: the first levels keep every lane busy, and the
-                // serial tail (one node per row at the top) is paid once per chunk, not per row.
-                // The children were stored by this workgroup: a barrier makes them visible (one
-                // CU, one L1; the lines were never read before they were written).
-                const uint32_t first = (round / a.rounds_per_chunk) * a.rounds_per_chunk;
-                const uint32_t nrows_c = round - first + 1;
-                const uint32_t depth = 31u - __builtin_clz(cw);
-                __syncthreads();
-                for (uint32_t lvl = LOGE + 1; lvl <= depth; lvl++) {
-                    const uint32_t wshift = depth - lvl;  // log2(width of this level)
-                    const uint32_t total = nrows_c << wshift;
-                    for (uint32_t idx = tid; idx < total; idx += T) {
-                        const uint32_t ri = idx >> wshift, i = idx & ((1u << wshift) - 1u);
-                        const uint32_t r = blockIdx.x + (first + ri) * gridDim.x;
-                        uint32_t *tree = a.layers + (size_t)r * (2u * cw) * 8;
-                        const uint32_t *ch = tree + ((size_t)level_off(cw, lvl - 1) + 2u * i) * 8;
-                        uint32_t l[8], rr[8], h[8];
-                        load_hash(ch, l);
-                        load_hash(ch + 8, rr);
-                        blake3_node(l, rr, h);
-                        store_hash(tree + ((size_t)level_off(cw, lvl) + i) * 8, h);
-                        if (lvl == depth) store_hash(a.roots + (size_t)r * 8, h);
-                    }
-                    __syncthreads();
-                }
-                if (depth == 0 && tid == 0) {  // a one-leaf tree: the root is the leaf hash
-                    for (uint32_t ri = 0; ri < nrows_c; ri++) {
-                        const uint32_t r = blockIdx.x + (first + ri) * gridDim.x;
-                        uint32_t h[8];
-                        load_hash(a.layers + (size_t)r * (2u * cw) * 8, h);
-                        store_hash(a.roots + (size_t)r * 8, h);
-                    }
-                }
-            }
-            if (a.chunk_done) {
-                __syncthreads();  // every wave's stores are issued and waited for (vmcnt(0) + barrier)
-                if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back has landed before the count moves
-                    __hip_atomic_fetch_add(&a.chunk_done[round / a.rounds_per_chunk], 1u, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-#ifdef ZIPK_DEBUG_STAMPS
-                    a.stamps[(round / a.rounds_per_chunk) * gridDim.x + blockIdx.x] = wall_clock64();
-#endif
-                }
-            }
+            finish_chunk<HASH>(a, LOGE + 1, round, tid, T);
         }
         if (prefetch && has_next) {
             // rowbuf was last read in pass 1 and every lane has finished with the planes: stage the
@@ -499,6 +508,138 @@ __global__ void __launch_bounds__(1024, (E <= 8 ? 5 : 4)) raa_commit_kernel(Comm
         o[0] = ph_a; o[1] = ph_b; o[2] = ph_c;
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------
+// cw = 16384 (the 2^26 geometry: row_len 8192, 1024 threads x 16 entries).  The intermediate
+// codeword t2 does not fit LDS as 96-bit values (196 KB), but it does in a compact form:
+//   t2[j] = P[j/16] + L[j]   (P = exclusive prefix of the thread that owns j, |L| < 2^67)
+// so bits 64.. of t2[j] differ from those of P[j/16] by at most +-9.  LDS holds the low 64 bits per
+// entry (planes, 128 KB), that difference as one byte per entry (16 KB) and the high word of P per
+// thread (2 KB): 146.5 KB, and pass 2 gathers pi2 from LDS like the smaller geometries do -- no
+// round trip of t2 through L2 and no store-draining barriers.  The witness row (64 KB) no longer
+// fits beside it and is gathered from global memory (L2) at the start of pass 1.
+// The output phase reuses the butterfly of raa_commit_kernel<8>: the row is emitted as two strips
+// of 8192 entries, each transposed through LDS (over the dead t2) to strided ownership.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kC16_T = 1024, kC16_PS = kC16_T + 2;  // plane stride of the 16 t2 planes
+constexpr uint32_t kC16_PS8 = kC16_T + 4;                // plane stride of the 8 output planes of one strip
+constexpr size_t kC16_LDS = 512 + (size_t)16 * kC16_PS * 8 + (size_t)16 * kC16_PS + (size_t)kC16_T * 4;
+
+template <bool HASH>
+__global__ void __launch_bounds__(1024, 4) raa_commit16_kernel(CommitArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int E = 16;
+    constexpr uint32_t T = kC16_T, PS = kC16_PS, PS8 = kC16_PS8;
+    const uint32_t tid0 = threadIdx.x;
+    const uint32_t cw = a.cw, row_len = a.row_len;  // 16384, 8192
+
+    i128 *wave_tot = reinterpret_cast<i128 *>(smem);
+    uint64_t *t2lo = reinterpret_cast<uint64_t *>(smem + 512);           // [16][PS]
+    int8_t *t2dh = reinterpret_cast<int8_t *>(t2lo + (size_t)E * PS);     // [16][PS]
+    int32_t *ghi = reinterpret_cast<int32_t *>(t2dh + (size_t)E * PS);    // [T]: bits 64.. of P[thread]
+    // output strips (phase B) overlay the same memory
+    uint64_t *o_lo = reinterpret_cast<uint64_t *>(smem + 512);            // [8][PS8]
+    uint32_t *o_hi = reinterpret_cast<uint32_t *>(o_lo + (size_t)8 * PS8);  // [8][PS8]
+
+    // row-invariant: pi1 source index (13 bits) | pi2 source entry (14 bits) per owned entry
+    uint32_t pidx[E];
+#pragma unroll
+    for (int e = 0; e < E; e++)
+        pidx[e] = (a.perm1[tid0 * E + e] & (row_len - 1)) | (a.perm2[tid0 * E + e] << 13);
+
+    uint32_t round = 0;
+    for (uint32_t row = blockIdx.x; row < a.num_rows; row += gridDim.x, round++) {
+        const uint32_t z = opaque_zero(row);
+        const uint32_t tid = tid0 + z;
+        const int64_t *in = a.evals + (size_t)row * row_len;
+        uint64_t *out_row = a.rows + (size_t)row * cw * 4;
+
+        i128 v[E];
+        // ---- pass 1: repeat + permute(pi1) + accumulate (witness from global / L2) ----
+#pragma unroll
+        for (int e = 0; e < E; e++) v[e] = (i128)in[pidx[e] & 0x1FFFu];
+#pragma unroll
+        for (int e = 1; e < E; e++) v[e] += v[e - 1];
+        {
+            if (round) lds_barrier();  // the previous row's output strips have been consumed
+            const i128 pre = block_exclusive_scan_i96(v[E - 1], wave_tot, 0);
+            const int32_t phi = (int32_t)(uint32_t)((u128)pre >> 64);
+            ghi[tid] = phi;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const i128 t = v[e] + pre;
+                t2lo[e * PS + tid] = (uint64_t)t;
+                t2dh[e * PS + tid] = (int8_t)((int32_t)(uint32_t)((u128)t >> 64) - phi);
+            }
+        }
+        lds_barrier();
+        // ---- pass 2: permute(pi2) + accumulate ----
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const uint32_t j = pidx[e] >> 13;
+            const uint32_t slot = (j & 15u) * PS + (j >> 4);
+            const uint64_t lo = t2lo[slot];
+            const int64_t hi = (int64_t)(ghi[j >> 4] + (int32_t)t2dh[slot]);
+            v[e] = (i128)(((u128)(uint64_t)hi << 64) | lo);
+        }
+#pragma unroll
+        for (int e = 1; e < E; e++) v[e] += v[e - 1];
+        {
+            // the barrier inside also orders the t2 reads above before the strip stores below
+            const i128 pre = block_exclusive_scan_i96(v[E - 1], wave_tot, 1);
+#pragma unroll
+            for (int e = 0; e < E; e++) v[e] += pre;
+        }
+        // the values wait in registers while the other strip is hashed: keep the 96 significant bits only
+        uint64_t flo[E];
+        uint32_t fhi[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            flo[e] = (uint64_t)v[e];
+            fhi[e] = (uint32_t)((u128)v[e] >> 64);
+        }
+        // ---- output: two strips of 8192 entries, each through LDS to strided ownership ----
+#pragma unroll 1
+        for (uint32_t h = 0; h < 2; h++) {
+            if (h) lds_barrier();  // strip 0 has been read by every lane
+            if ((tid >> 9) == h) {
+                const uint32_t t9 = tid & 511u;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const uint32_t jj = t9 * E + e;  // entry inside the strip
+                    const uint32_t slot = (jj & 7u) * PS8 + (jj >> 3);
+                    o_lo[slot] = flo[e];
+                    o_hi[slot] = fhi[e];
+                }
+            }
+            lds_barrier();
+            StridedLeaves<8> src;
+            src.out_row = out_row;
+            src.tree = HASH ? a.layers + (size_t)row * (2u * cw) * 8 : nullptr;
+            src.cw = cw;
+            src.T = T;
+            src.tid = tid;
+            src.base = h * 8192u;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint32_t jj = e * T + tid;
+                const uint32_t slot = (jj & 7u) * PS8 + (jj >> 3);
+                const uint64_t lo = o_lo[slot];
+                src.w0[e] = (uint32_t)lo;
+                src.w1[e] = (uint32_t)(lo >> 32);
+                src.w2[e] = o_hi[slot];
+            }
+            if (HASH) {
+                uint32_t top[8];
+                bfly_hash<3, 0>(src, top);
+            } else {
+                store_rows_only<8, 0>(src);
+            }
+        }
+        const bool last = row + gridDim.x >= a.num_rows;
+        if (last || (round + 1) % a.rounds_per_chunk == 0) finish_chunk<HASH>(a, 4u, round, tid, T);
+    }
 }
 
 // One wave that parks a stream until `*counter >= target` (a chunk of the persistent commit

@@ -475,6 +475,8 @@ CommitGeom commit_geom(uint32_t cw, uint32_t row_len) {
     else if (cw == 128) { g.e = 2; g.threads = 64; g.levels_done = 1; g.t2_lds = true; }
     else { g.e = 1; g.threads = 64; g.levels_done = 0; g.t2_lds = true; }  // cw <= 64: one entry per lane
     g.lds = 512 + (g.t2_lds ? (size_t)g.e * (g.threads + 32 / g.e) * 12 + (size_t)row_len * 8 : 0);
+    static const bool old16 = getenv("ZIP_HIP_OLD16") != nullptr;  // A/B: the variant that parks t2 in the output row
+    if (cw == 16384 && row_len == 8192 && !old16) g.lds = kC16_LDS;  // raa_commit16_kernel (compact t2 in LDS)
     return g;
 }
 // resident workgroups per CU of the commit kernel (threads and LDS)
@@ -490,7 +492,21 @@ int32_t dispatch_commit(zip_ctx *ctx, CommitArgs a, uint32_t grid, hipStream_t s
     const CommitGeom g = commit_geom(a.cw, a.row_len);
     a.nact = a.cw / g.e < g.threads ? a.cw / g.e : g.threads;
     switch (g.e) {
-        case 16: return launch_commit<16, HASH, false>(ctx, a, g.threads, grid, st);
+        case 16:
+            if (g.lds == kC16_LDS) {
+                auto kern = raa_commit16_kernel<HASH>;
+                static bool attr = false;
+                if (!attr) {
+                    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC16_LDS));
+                    attr = true;
+                }
+                LaunchTimer t(ctx, HASH ? "raa_commit_kernel" : "raa_encode_kernel", st);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), kC16_LDS, st, a);
+                HIP_TRY(ctx, hipGetLastError());
+                return ZIP_OK;
+            }
+            return launch_commit<16, HASH, false>(ctx, a, g.threads, grid, st);
         case 8: return launch_commit<8, HASH, true>(ctx, a, g.threads, grid, st);
         case 4: return launch_commit<4, HASH, true>(ctx, a, g.threads, grid, st);
         case 2: return launch_commit<2, HASH, true>(ctx, a, g.threads, grid, st);
