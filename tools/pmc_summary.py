@@ -65,7 +65,7 @@ def main():
         wk = sum(write.get(k, [0])) / max(len(write.get(k, [])), 1)
         b2, b1 = int((2 * fk + wk) * 1024), int((fk + wk) * 1024)
         lines.append(f"| `{k[:70]}` | {len(fetch.get(k, write.get(k, [])))} | {fk:,.0f} | {wk:,.0f} | {b2:,} | {b1:,} |")
-        short = "raa_commit_kernel" if "raa_commit_kernel" in k and "true, true" in k else (
+        short = "raa_commit_kernel" if "raa_commit_kernel<" in k and ", true>" in k else (
             "open_columns_kernel" if "open_columns_kernel" in k else None)
         if short:
             traffic[short] = {"num_vars": a.num_vars, "fetch_kib": fk, "write_kib": wk,

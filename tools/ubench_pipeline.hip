@@ -45,7 +45,7 @@ int main() {
     a.evals = evd; a.perm1 = p1d; a.perm2 = p2d; a.row_len = C; a.cw = cw; a.nact = cw / 8;
     a.num_rows = R; a.rounds_per_chunk = rpc; a.stamps = stamps_h; CK(hipMalloc(&a.roots, R * 32));
     const size_t lds = 512 + (size_t)8 * (1024 + 4) * 12 + (size_t)C * 8;
-    auto kh = raa_commit_kernel<8, true, true>;
+    auto kh = raa_commit_kernel<8, true>;
     CK(hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

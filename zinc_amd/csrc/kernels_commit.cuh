@@ -138,23 +138,6 @@ __device__ __forceinline__ void subtree_hash(Src &src, uint32_t (&h)[8]) {
     }
 }
 
-// Leaves / node sink of one thread of raa_commit_kernel: E consecutive codeword entries.
-template <int E>
-struct CommitLeaves {
-    const i128 (&v)[E];
-    uint32_t *tree;
-    uint32_t cw, j0;
-    template <int E0>
-    __device__ __forceinline__ void leaf(uint32_t (&h)[8]) {
-        blake3_leaf_sext96((uint32_t)v[E0], (uint32_t)((u128)v[E0] >> 32), (uint32_t)((u128)v[E0] >> 64), h);
-        store_hash(tree + (size_t)(j0 + E0) * 8, h);
-    }
-    __device__ __forceinline__ void store(int lvl, uint32_t idx, const uint32_t (&h)[8]) {
-        store_hash(tree + ((size_t)level_off(cw, lvl) + (j0 >> lvl) + idx) * 8, h);
-    }
-};
-
-
 // Strided ownership for the output phase: at step e lane t owns codeword entry
 // j = e*T + t, so the 32-byte row entries, leaf hashes and nodes that a wave stores in one
 // instruction are adjacent in memory (4 lanes per 128-byte line instead of one lane per
@@ -289,11 +272,8 @@ __device__ __forceinline__ uint32_t opaque_zero(uint32_t dep) {
 // entries [t*E, t*E+E) during the two scans.  Values never exceed 64 + 2*log2(cw) + 1 <= 96
 // bits (width assertion src/zip/code_raa.rs:53-72), so the scans run on i128 lanes and the
 // 256-bit result is the sign extension.
-//   T2_LDS = true : witness row and the intermediate codeword t2 live in LDS
-//                   (cw*12 + row_len*8 bytes; up to cw = 8192).
-//   T2_LDS = false: t2 is parked in the (not yet written) output row in HBM/L2
-//                   and the witness row is gathered from global memory.
-// In LDS, entry j sits at slot (j % E) * (T + 32/E) + j / E: the thread-contiguous writes
+// The witness row and the intermediate codeword t2 live in LDS (cw*12 + row_len*8 bytes; up to
+// cw = 8192 -- cw = 16384 has its own kernel below).  In LDS, entry j sits at slot (j % E) * (T + 32/E) + j / E: the thread-contiguous writes
 // of a wave are bank-conflict free, and so are the strided reads (entry e*T + t) of the
 // output phase; the pi2 gather is random either way.
 //
@@ -308,11 +288,11 @@ __device__ __forceinline__ uint32_t opaque_zero(uint32_t dep) {
 // (second __launch_bounds__ argument = waves per SIMD) leaves a quarter of every SIMD register
 // file to the consumer kernels.  At 128 VGPRs the file is full and nothing can co-reside
 // (measured: a probe kernel on another stream then only runs when this kernel ends).
-template <int E, bool HASH, bool T2_LDS>
-__global__ void __launch_bounds__(1024, (E <= 8 ? 5 : 4)) raa_commit_kernel(CommitArgs a) {
+template <int E, bool HASH>
+__global__ void __launch_bounds__(1024, 5) raa_commit_kernel(CommitArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int LOGE = (E == 1) ? 0 : (E == 2) ? 1 : (E == 4) ? 2 : (E == 8) ? 3 : 4;
-    static_assert((1 << LOGE) == E, "E must be a power of two <= 16");
+    constexpr int LOGE = (E == 1) ? 0 : (E == 2) ? 1 : (E == 4) ? 2 : 3;
+    static_assert((1 << LOGE) == E && E <= 8, "E must be 1, 2, 4 or 8");
 
     const uint32_t tid0 = threadIdx.x, T = blockDim.x;
     constexpr uint32_t PAD = 32 / E;
@@ -322,28 +302,26 @@ __global__ void __launch_bounds__(1024, (E <= 8 ? 5 : 4)) raa_commit_kernel(Comm
 
     i128 *wave_tot = reinterpret_cast<i128 *>(smem);                  // 2 x 16 entries
     uint64_t *t2lo = reinterpret_cast<uint64_t *>(smem + 512);         // E planes of PS slots
-    uint32_t *t2hi = reinterpret_cast<uint32_t *>(t2lo + (T2_LDS ? E * PS : 0));
-    int64_t *rowbuf = reinterpret_cast<int64_t *>(t2hi + (T2_LDS ? E * PS : 0));
+    uint32_t *t2hi = reinterpret_cast<uint32_t *>(t2lo + E * PS);
+    int64_t *rowbuf = reinterpret_cast<int64_t *>(t2hi + E * PS);
 
     // Row-invariant state kept in registers so that no global load sits on the per-row critical
     // path: the thread's permutation indices (packed: pi1 source index | pi2 LDS slot << 16) ...
     uint32_t pidx[E];
-    if (T2_LDS) {
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            uint32_t v1 = 0, v2 = 0;
-            if (active) {
-                v1 = a.perm1[tid0 * E + e] & (row_len - 1);  // repeat: t0[j] = row[j mod row_len]
-                const uint32_t p2 = a.perm2[tid0 * E + e];
-                v2 = (p2 & (E - 1)) * PS + (p2 >> LOGE);
-            }
-            pidx[e] = v1 | (v2 << 16);
+    for (int e = 0; e < E; e++) {
+        uint32_t v1 = 0, v2 = 0;
+        if (active) {
+            v1 = a.perm1[tid0 * E + e] & (row_len - 1);  // repeat: t0[j] = row[j mod row_len]
+            const uint32_t p2 = a.perm2[tid0 * E + e];
+            v2 = (p2 & (E - 1)) * PS + (p2 >> LOGE);
         }
+        pidx[e] = v1 | (v2 << 16);
     }
     // ... and the NEXT witness row, fetched while the current one is being hashed (rep = 2
     // geometry: row_len == NPF * blockDim; anything else takes the direct path).
     constexpr int NPF = (E >= 2) ? E / 2 : 1;
-    const bool prefetch = T2_LDS && row_len == NPF * T;
+    const bool prefetch = row_len == NPF * T;
     int64_t nxt[NPF];
 
 #ifdef ZIPK_DEBUG_STAMPS
@@ -358,12 +336,11 @@ __global__ void __launch_bounds__(1024, (E <= 8 ? 5 : 4)) raa_commit_kernel(Comm
         ph_t = wall_clock64();
 #endif
         const uint32_t z = opaque_zero(row);
-        const uint32_t tid = tid0 + z, j0 = tid * E;
+        const uint32_t tid = tid0 + z;
         const int64_t *in = a.evals + (size_t)row * row_len;
         uint64_t *out_row = a.rows + (size_t)row * cw * 4;
-        u128 *t2g = reinterpret_cast<u128 *>(out_row);  // T2_LDS == false: first half of the output row
 
-        if (T2_LDS && !(prefetch && round)) {
+        if (!(prefetch && round)) {
             if (round) lds_barrier();  // the previous row's LDS image has been consumed
             for (uint32_t i = tid; i < row_len; i += T) rowbuf[i] = in[i];
             lds_barrier();
@@ -373,14 +350,7 @@ __global__ void __launch_bounds__(1024, (E <= 8 ? 5 : 4)) raa_commit_kernel(Comm
         // ---- pass 1: repeat + permute(pi1) + accumulate ------------------------
         if (active) {
 #pragma unroll
-            for (int e = 0; e < E; e++) {
-                if (T2_LDS) {
-                    v[e] = (i128)rowbuf[pidx[e] & 0xFFFFu];
-                } else {
-                    const uint32_t src = a.perm1[j0 + e] & (row_len - 1);
-                    v[e] = (i128)in[src];
-                }
-            }
+            for (int e = 0; e < E; e++) v[e] = (i128)rowbuf[pidx[e] & 0xFFFFu];
 #pragma unroll
             for (int e = 1; e < E; e++) v[e] += v[e - 1];
         } else {
@@ -393,29 +363,21 @@ __global__ void __launch_bounds__(1024, (E <= 8 ? 5 : 4)) raa_commit_kernel(Comm
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     v[e] += pre;
-                    if (T2_LDS) {
-                        const uint32_t slot = e * PS + tid;
-                        t2lo[slot] = (uint64_t)v[e];
-                        t2hi[slot] = (uint32_t)((u128)v[e] >> 64);
-                    } else {
-                        t2g[j0 + e] = (u128)v[e];
-                    }
+                    const uint32_t slot = e * PS + tid;
+                    t2lo[slot] = (uint64_t)v[e];
+                    t2hi[slot] = (uint32_t)((u128)v[e] >> 64);
                 }
             }
         }
-        if (T2_LDS) lds_barrier(); else __syncthreads();  // the global t2 needs the full fence
+        lds_barrier();
         // ---- pass 2: permute(pi2) + accumulate ---------------------------------
         if (active) {
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                if (T2_LDS) {
-                    const uint32_t slot = pidx[e] >> 16;
-                    const uint64_t lo = t2lo[slot];
-                    const int64_t hi = (int64_t)(int32_t)t2hi[slot];
-                    v[e] = (i128)(((u128)(uint64_t)hi << 64) | lo);
-                } else {
-                    v[e] = (i128)t2g[a.perm2[j0 + e]];
-                }
+                const uint32_t slot = pidx[e] >> 16;
+                const uint64_t lo = t2lo[slot];
+                const int64_t hi = (int64_t)(int32_t)t2hi[slot];
+                v[e] = (i128)(((u128)(uint64_t)hi << 64) | lo);
             }
 #pragma unroll
             for (int e = 1; e < E; e++) v[e] += v[e - 1];
@@ -426,67 +388,47 @@ __global__ void __launch_bounds__(1024, (E <= 8 ? 5 : 4)) raa_commit_kernel(Comm
 #pragma unroll
             for (int e = 0; e < E; e++) v[e] += pre;
         }
-        if (!T2_LDS) __syncthreads();  // every lane has read its t2 entries before the row is overwritten
 
         const bool has_next = row + gridDim.x < a.num_rows;
-        if (T2_LDS) {
-            // ---- transpose to strided ownership through LDS, then rows + hashes ------
-            if (active) {
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    const uint32_t slot = e * PS + tid;
-                    t2lo[slot] = (uint64_t)v[e];
-                    t2hi[slot] = (uint32_t)((u128)v[e] >> 64);
-                }
-            }
-            lds_barrier();
-            if (prefetch && has_next) {  // in flight during the whole hash phase
-                const int64_t *nin = a.evals + (size_t)(row + gridDim.x) * row_len;
-#pragma unroll
-                for (int k = 0; k < NPF; k++) nxt[k] = nin[k * T + tid];
-            }
-            ZIPK_PH(ph_a);
-            if (active) {
-                StridedLeaves<E> src;
-                src.out_row = out_row;
-                src.tree = HASH ? a.layers + (size_t)row * (2u * cw) * 8 : nullptr;
-                src.cw = cw;
-                src.T = a.nact;
-                src.tid = tid;
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    const uint32_t j = e * a.nact + tid;
-                    const uint32_t slot = (j & (E - 1)) * PS + (j >> LOGE);
-                    const uint64_t lo = t2lo[slot];
-                    src.w0[e] = (uint32_t)lo;
-                    src.w1[e] = (uint32_t)(lo >> 32);
-                    src.w2[e] = t2hi[slot];
-                }
-                if (HASH) {
-                    uint32_t top[8];
-                    bfly_hash<LOGE, 0>(src, top);
-                } else {
-                    store_rows_only<E, 0>(src);
-                }
-            }
-        } else if (active) {
-            // ---- thread-contiguous outputs (cw too large for the LDS transposition) -----
-            uint4 *orow = reinterpret_cast<uint4 *>(out_row + (size_t)j0 * 4);
+        // ---- transpose to strided ownership through LDS, then rows + hashes ------
+        if (active) {
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const uint32_t d0 = (uint32_t)v[e], d1 = (uint32_t)((u128)v[e] >> 32),
-                               d2 = (uint32_t)((u128)v[e] >> 64);
-                const uint32_t sg = (uint32_t)((int32_t)d2 >> 31);
-                orow[2 * e] = make_uint4(d0, d1, d2, sg);
-                orow[2 * e + 1] = make_uint4(sg, sg, sg, sg);
-            }
-            if (HASH) {
-                CommitLeaves<E> src{v, a.layers + (size_t)row * (2u * cw) * 8, cw, j0};
-                uint32_t top[8];
-                subtree_hash<LOGE, 0>(src, top);
+                const uint32_t slot = e * PS + tid;
+                t2lo[slot] = (uint64_t)v[e];
+                t2hi[slot] = (uint32_t)((u128)v[e] >> 64);
             }
         }
-
+        lds_barrier();
+        if (prefetch && has_next) {  // in flight during the whole hash phase
+            const int64_t *nin = a.evals + (size_t)(row + gridDim.x) * row_len;
+#pragma unroll
+            for (int k = 0; k < NPF; k++) nxt[k] = nin[k * T + tid];
+        }
+        ZIPK_PH(ph_a);
+        if (active) {
+            StridedLeaves<E> src;
+            src.out_row = out_row;
+            src.tree = HASH ? a.layers + (size_t)row * (2u * cw) * 8 : nullptr;
+            src.cw = cw;
+            src.T = a.nact;
+            src.tid = tid;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const uint32_t j = e * a.nact + tid;
+                const uint32_t slot = (j & (E - 1)) * PS + (j >> LOGE);
+                const uint64_t lo = t2lo[slot];
+                src.w0[e] = (uint32_t)lo;
+                src.w1[e] = (uint32_t)(lo >> 32);
+                src.w2[e] = t2hi[slot];
+            }
+            if (HASH) {
+                uint32_t top[8];
+                bfly_hash<LOGE, 0>(src, top);
+            } else {
+                store_rows_only<E, 0>(src);
+            }
+        }
         ZIPK_PH(ph_b);
         // ---- finish a chunk: upper Merkle levels of this workgroup's rows, then publish ------
         const bool last = row + gridDim.x >= a.num_rows;

@@ -445,11 +445,11 @@ FieldDev<FL> to_dev(const HostField &h) {
 
 // ------------------------------------------------------------------ commit dispatch
 // Persistent launch: as many workgroups as stay resident together (at most one per row).
-template <int E, bool HASH, bool T2_LDS>
+template <int E, bool HASH>
 int32_t launch_commit(zip_ctx *ctx, const CommitArgs &a, uint32_t threads, uint32_t grid, hipStream_t st) {
     // wave totals + E planes of (threads + 32/E) slots of 12 bytes + the witness row
-    const size_t lds = 512 + (T2_LDS ? (size_t)E * (threads + 32 / E) * 12 + (size_t)a.row_len * 8 : 0);
-    auto kern = raa_commit_kernel<E, HASH, T2_LDS>;
+    const size_t lds = 512 + (size_t)E * (threads + 32 / E) * 12 + (size_t)a.row_len * 8;
+    auto kern = raa_commit_kernel<E, HASH>;
     static size_t lds_attr = 0;  // per instantiation
     if (lds > lds_attr) {
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -462,21 +462,34 @@ int32_t launch_commit(zip_ctx *ctx, const CommitArgs &a, uint32_t threads, uint3
     return ZIP_OK;
 }
 
+// cw = 16384: raa_commit16_kernel (t2 compacted into LDS, 1024 threads x 16 entries)
+template <bool HASH>
+int32_t launch_commit16(zip_ctx *ctx, const CommitArgs &a, uint32_t grid, hipStream_t st) {
+    auto kern = raa_commit16_kernel<HASH>;
+    static bool attr = false;
+    if (!attr) {
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC16_LDS));
+        attr = true;
+    }
+    LaunchTimer t(ctx, HASH ? "raa_commit_kernel" : "raa_encode_kernel", st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), kC16_LDS, st, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return ZIP_OK;
+}
+
 struct CommitGeom {
-    uint32_t e, threads, levels_done;
-    bool t2_lds;
+    uint32_t e, threads;
     size_t lds;
 };
 CommitGeom commit_geom(uint32_t cw, uint32_t row_len) {
     CommitGeom g{};
-    if (cw == 16384) { g.e = 16; g.threads = 1024; g.levels_done = 4; g.t2_lds = false; }
-    else if (cw >= 512) { g.e = 8; g.threads = cw / 8; g.levels_done = 3; g.t2_lds = true; }
-    else if (cw == 256) { g.e = 4; g.threads = 64; g.levels_done = 2; g.t2_lds = true; }
-    else if (cw == 128) { g.e = 2; g.threads = 64; g.levels_done = 1; g.t2_lds = true; }
-    else { g.e = 1; g.threads = 64; g.levels_done = 0; g.t2_lds = true; }  // cw <= 64: one entry per lane
-    g.lds = 512 + (g.t2_lds ? (size_t)g.e * (g.threads + 32 / g.e) * 12 + (size_t)row_len * 8 : 0);
-    static const bool old16 = getenv("ZIP_HIP_OLD16") != nullptr;  // A/B: the variant that parks t2 in the output row
-    if (cw == 16384 && row_len == 8192 && !old16) g.lds = kC16_LDS;  // raa_commit16_kernel (compact t2 in LDS)
+    if (cw == 16384) { g.e = 16; g.threads = 1024; g.lds = kC16_LDS; return g; }
+    if (cw >= 512) { g.e = 8; g.threads = cw / 8; }
+    else if (cw == 256) { g.e = 4; g.threads = 64; }
+    else if (cw == 128) { g.e = 2; g.threads = 64; }
+    else { g.e = 1; g.threads = 64; }  // cw <= 64: one entry per lane
+    g.lds = 512 + (size_t)g.e * (g.threads + 32 / g.e) * 12 + (size_t)row_len * 8;
     return g;
 }
 // resident workgroups per CU of the commit kernel (threads and LDS)
@@ -492,25 +505,11 @@ int32_t dispatch_commit(zip_ctx *ctx, CommitArgs a, uint32_t grid, hipStream_t s
     const CommitGeom g = commit_geom(a.cw, a.row_len);
     a.nact = a.cw / g.e < g.threads ? a.cw / g.e : g.threads;
     switch (g.e) {
-        case 16:
-            if (g.lds == kC16_LDS) {
-                auto kern = raa_commit16_kernel<HASH>;
-                static bool attr = false;
-                if (!attr) {
-                    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC16_LDS));
-                    attr = true;
-                }
-                LaunchTimer t(ctx, HASH ? "raa_commit_kernel" : "raa_encode_kernel", st);
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), kC16_LDS, st, a);
-                HIP_TRY(ctx, hipGetLastError());
-                return ZIP_OK;
-            }
-            return launch_commit<16, HASH, false>(ctx, a, g.threads, grid, st);
-        case 8: return launch_commit<8, HASH, true>(ctx, a, g.threads, grid, st);
-        case 4: return launch_commit<4, HASH, true>(ctx, a, g.threads, grid, st);
-        case 2: return launch_commit<2, HASH, true>(ctx, a, g.threads, grid, st);
-        default: return launch_commit<1, HASH, true>(ctx, a, g.threads, grid, st);
+        case 16: return launch_commit16<HASH>(ctx, a, grid, st);
+        case 8: return launch_commit<8, HASH>(ctx, a, g.threads, grid, st);
+        case 4: return launch_commit<4, HASH>(ctx, a, g.threads, grid, st);
+        case 2: return launch_commit<2, HASH>(ctx, a, g.threads, grid, st);
+        default: return launch_commit<1, HASH>(ctx, a, g.threads, grid, st);
     }
 }
 
