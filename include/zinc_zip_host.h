@@ -64,6 +64,18 @@ void zinc_zip_params_geometry(const zinc_zip_params *pp, uint32_t *num_vars, uin
 int32_t zinc_zip_commit(const zinc_zip_params *pp, const int64_t *evals, size_t n_evals, uint32_t poly_num_vars,
                         int32_t with_merkle, uint8_t *roots_out, zinc_zip_data **out);
 void zinc_zip_data_free(zinc_zip_data *d);
+/* MultilinearZipData is `pub rows` / `pub rows_merkle_trees` in the reference (structs.rs:33-38) and its
+ * tests read and mutate both: these move them between the host and the device handle.
+ *   rows    num_rows * codeword_len Int<4>  (4 u64 each)
+ *   layers  per row (2 * codeword_len - 2) hashes = MerkleTree.layers (pcs/utils.rs:67-71)
+ *   roots   per row one hash.  Any pointer may be NULL on download; layers / roots NULL on upload = no trees. */
+int32_t zinc_zip_data_download(const zinc_zip_data *d, uint64_t *rows_out, uint8_t *layers_out, uint8_t *roots_out);
+int32_t zinc_zip_data_upload(const zinc_zip_params *pp, const uint64_t *rows, const uint8_t *layers,
+                             const uint8_t *roots, zinc_zip_data **out);
+/* MerkleTree::new(depth, leaves) (pcs/utils.rs:74-85) for n_leaves Int<leaf_limbs>; layers_out: (2 << depth) - 1
+ * hashes, the root last.  ZINC_ERR_PANIC when n_leaves != 2^depth ("leaves.len().is_power_of_two()" / depth assert). */
+int32_t zinc_merkle_tree_new(uint32_t depth, const uint64_t *leaves, size_t n_leaves, uint32_t leaf_limbs,
+                             int32_t device, uint8_t *layers_out);
 
 /* PcsTranscript (src/zip/pcs_transcript.rs) */
 typedef struct zinc_pcs_transcript zinc_pcs_transcript;

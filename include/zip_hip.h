@@ -175,8 +175,10 @@ int32_t zip_open_stream(zip_commitment *c, const int64_t *evals, zip_mem_kind ev
  * Deliberate differences from the reference, both on the rejecting side:
  *  - Merkle paths ARE checked (the reference computes the check and drops the result,
  *    verify_z.rs:99, but then loses its place in the stream at the first bad path);
- *  - evaluation-row elements >= q are rejected as malformed (the reference does not range-check
- *    them; its sequential modular additions then depend on the representation).
+ *  - evaluation-row elements >= q that survive the evaluation-consistency check (which is
+ *    representation independent and comes first, as in the reference) are rejected as malformed; the
+ *    reference does not range-check them and its sequential modular additions in encode_f then
+ *    depend on the representation.
  * The function result is only non-zero for usage / device errors. */
 typedef enum {
     ZIP_VERIFY_ACCEPT = 0,

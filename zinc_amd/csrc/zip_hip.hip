@@ -1555,13 +1555,15 @@ int32_t zip_verify(zip_ctx *ctx, const uint8_t *roots, const uint8_t *proof, zip
         if (malformed[i]) { report->verdict = ZIP_VERIFY_MALFORMED; report->column = i; return ZIP_OK; }
         if (bad[i]) { report->verdict = ZIP_VERIFY_MERKLE; report->column = i; return ZIP_OK; }
     }
-    if (cnt.noncanonical) { report->verdict = ZIP_VERIFY_MALFORMED; return ZIP_OK; }
+    // <row, q1> is a Montgomery product per element and therefore well defined for elements >= q too:
+    // the consistency check comes first, as in the reference (verify_z.rs:145-149)
     if (C > 1 ? memcmp(cnt.dot, eval_mont, 8 * hf.fl) != 0 : [&] {
             for (uint32_t i = 0; i < hf.fl; i++) if (eval_mont[i]) return true;
             return false; }()) {
         report->verdict = ZIP_VERIFY_EVAL_CONSISTENCY;
         return ZIP_OK;
     }
+    if (cnt.noncanonical) { report->verdict = ZIP_VERIFY_MALFORMED; return ZIP_OK; }
     for (uint32_t i = 0; i < n_cols; i++)
         if (flags[i] & 2u) { report->verdict = ZIP_VERIFY_PROXIMITY_Q0; report->column = i; return ZIP_OK; }
     report->verdict = ZIP_VERIFY_ACCEPT;

@@ -159,6 +159,40 @@ int32_t zinc_zip_commit(const zinc_zip_params *pp, const int64_t *evals, size_t 
 }
 void zinc_zip_data_free(zinc_zip_data *d) { delete d; }
 
+int32_t zinc_zip_data_download(const zinc_zip_data *d, uint64_t *rows_out, uint8_t *layers_out, uint8_t *roots_out) {
+    if (!d) return ZINC_ERR_NULL;
+    return guarded([&] {
+        const int32_t rc = zip_commit_download(d->d.handle.get(), rows_out, layers_out, roots_out);
+        if (rc) throw ZipError(ZipError::Device, std::string("zip_commit_download: ") + zip_ctx_last_error(d->d.ctx.get()));
+    });
+}
+
+int32_t zinc_zip_data_upload(const zinc_zip_params *pp, const uint64_t *rows, const uint8_t *layers,
+                             const uint8_t *roots, zinc_zip_data **out) {
+    if (!pp || !rows || !out) return ZINC_ERR_NULL;
+    *out = nullptr;
+    return guarded([&] {
+        zip_commitment *h = nullptr;
+        const int32_t rc = zip_commitment_upload(pp->pp.ctx.get(), rows, layers, roots, &h);
+        if (rc) throw ZipError(ZipError::Device, std::string("zip_commitment_upload: ") + zip_ctx_last_error(pp->pp.ctx.get()));
+        MultilinearZipData data;
+        data.ctx = pp->pp.ctx;
+        data.handle = std::shared_ptr<zip_commitment>(h, zip_commitment_free);
+        *out = new zinc_zip_data{std::move(data)};
+    });
+}
+
+int32_t zinc_merkle_tree_new(uint32_t depth, const uint64_t *leaves, size_t n_leaves, uint32_t leaf_limbs,
+                             int32_t device, uint8_t *layers_out) {
+    if (!leaves || !layers_out) return ZINC_ERR_NULL;
+    return guarded([&] {
+        if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) throw std::logic_error("assertion failed: leaves.len().is_power_of_two()");
+        if (n_leaves != ((size_t)1 << depth)) throw std::logic_error("assertion failed: leaves.len() == 1 << merkle_depth");
+        const int32_t rc = zip_merkle_trees(device, leaves, leaf_limbs, depth, 1, ZIP_MEM_HOST, layers_out);
+        if (rc) throw ZipError(ZipError::Device, std::string("zip_merkle_trees: ") + zip_strerror(rc));
+    });
+}
+
 zinc_pcs_transcript *zinc_pcs_transcript_new(void) { return new zinc_pcs_transcript(); }
 void zinc_pcs_transcript_free(zinc_pcs_transcript *t) { delete t; }
 size_t zinc_pcs_transcript_len(const zinc_pcs_transcript *t) { return t->t.stream.size(); }

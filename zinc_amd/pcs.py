@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "zinc_pcs_transcript_free", "zinc_pcs_transcript_len", "zinc_pcs_transcript_copy",
     "zinc_pcs_transcript_probe", "zinc_zip_open", "zinc_pcs_transcript_from_proof", "zinc_pcs_transcript_position",
     "zinc_zip_verify", "zinc_zip_evaluate", "zinc_commit_z_mle_and_prove_evaluation", "zinc_zip_proof_len",
-    "zinc_zip_proof_num_roots", "zinc_zip_proof_read", "zinc_zip_proof_free", "zinc_zip_release_cached_contexts", "zinc_sumcheck_prove_product",
+    "zinc_zip_proof_num_roots", "zinc_zip_proof_read", "zinc_zip_proof_free", "zinc_zip_release_cached_contexts", "zinc_sumcheck_prove_product", "zinc_zip_data_download", "zinc_zip_data_upload", "zinc_merkle_tree_new",
 )
 
 
@@ -100,6 +100,9 @@ def lib():
         L.zinc_zip_proof_read.argtypes = [vp, vp, vp, vp]
         L.zinc_zip_proof_read.restype = None
         L.zinc_zip_proof_free.argtypes = [vp]
+        L.zinc_zip_data_download.argtypes = [vp, vp, vp, vp]
+        L.zinc_zip_data_upload.argtypes = [vp, vp, vp, vp, C.POINTER(vp)]
+        L.zinc_merkle_tree_new.argtypes = [C.c_uint32, vp, C.c_size_t, C.c_uint32, C.c_int32, vp]
         L.zinc_sumcheck_prove_product.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_int32, vp, vp]
         _lib = L
     return _lib
@@ -229,9 +232,54 @@ class PcsTranscript:
         return lib().zinc_pcs_transcript_probe(self._h)
 
 
+class MerkleTree:
+    """MerkleTree {root, depth, layers} (src/zip/pcs/utils.rs:67-85)."""
+
+    def __init__(self, depth: int, layers: np.ndarray, root: np.ndarray):
+        self.depth, self.layers, self.root = depth, layers, root
+
+    @classmethod
+    def new(cls, depth: int, leaves, device: int = 0) -> "MerkleTree":
+        lv = np.ascontiguousarray(leaves, dtype=np.uint64)
+        lv = lv.reshape(lv.shape[0], -1)
+        out = np.zeros(((2 << depth) - 1, 32), np.uint8)
+        _check(lib().zinc_merkle_tree_new(depth, lv.ctypes.data, lv.shape[0], lv.shape[1], device, out.ctypes.data))
+        return cls(depth, out[:-1], out[-1])
+
+
 class MultilinearZipData:
-    def __init__(self, handle):
-        self._h = handle
+    """MultilinearZipData {rows, rows_merkle_trees} (structs.rs:33-38), resident on the device; `rows` and
+    `rows_merkle_trees` copy it to the host, `new` builds a handle from (possibly modified) host data."""
+
+    def __init__(self, handle, pp=None, has_trees=True):
+        self._h, self._pp, self._has_trees = handle, pp, has_trees
+
+    @property
+    def rows(self) -> np.ndarray:
+        pp = self._pp
+        out = np.zeros((pp.num_rows * pp.codeword_len, 4), np.uint64)
+        _check(lib().zinc_zip_data_download(self._h, out.ctypes.data, None, None))
+        return out
+
+    @property
+    def rows_merkle_trees(self):
+        pp = self._pp
+        if not self._has_trees:
+            return []
+        depth = pp.codeword_len.bit_length() - 1
+        layers = np.zeros((pp.num_rows, 2 * pp.codeword_len - 2, 32), np.uint8)
+        roots = np.zeros((pp.num_rows, 32), np.uint8)
+        _check(lib().zinc_zip_data_download(self._h, None, layers.ctypes.data, roots.ctypes.data))
+        return [MerkleTree(depth, layers[r], roots[r]) for r in range(pp.num_rows)]
+
+    @classmethod
+    def new(cls, pp, rows, rows_merkle_trees) -> "MultilinearZipData":
+        r = np.ascontiguousarray(rows, dtype=np.uint64)
+        layers = np.ascontiguousarray(np.stack([t.layers for t in rows_merkle_trees]), dtype=np.uint8)
+        roots = np.ascontiguousarray(np.stack([t.root for t in rows_merkle_trees]), dtype=np.uint8)
+        h = C.c_void_p()
+        _check(lib().zinc_zip_data_upload(pp._h, r.ctypes.data, layers.ctypes.data, roots.ctypes.data, C.byref(h)))
+        return cls(h, pp, True)
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -266,7 +314,35 @@ class MultilinearZip:
         roots = np.zeros((pp.num_rows, 32), np.uint8)
         h = C.c_void_p()
         _check(lib().zinc_zip_commit(pp._h, ev.ctypes.data, ev.size, nv, int(with_merkle), roots.ctypes.data, C.byref(h)))
-        return MultilinearZipData(h), (roots if with_merkle else None)
+        return MultilinearZipData(h, pp, with_merkle), (roots if with_merkle else None)
+
+    @staticmethod
+    def commit_no_merkle(pp: MultilinearZipParams, evaluations, num_vars: int = None):
+        """commit.rs:104-119: (data with empty trees, commitment with no roots)"""
+        data, _ = MultilinearZip.commit(pp, evaluations, num_vars, with_merkle=False)
+        return data, np.zeros((0, 32), np.uint8)
+
+    @staticmethod
+    def encode_rows(pp: MultilinearZipParams, evaluations) -> np.ndarray:
+        """commit.rs:158-183: the encoded rows as a flat vector of Int<4>"""
+        return MultilinearZip.commit_no_merkle(pp, evaluations)[0].rows
+
+    @staticmethod
+    def batch_commit(pp: MultilinearZipParams, polys):
+        """commit.rs:134-142: a plain loop over the polynomials"""
+        return [MultilinearZip.commit(pp, p) for p in polys]
+
+    @staticmethod
+    def batch_open(pp: MultilinearZipParams, polys, datas, points, field: "FieldConfig", transcript: "PcsTranscript"):
+        """open_z.rs:43-58"""
+        for p, d, pt in zip(polys, datas, points):
+            MultilinearZip.open(pp, p, d, pt, field, transcript)
+
+    @staticmethod
+    def batch_verify_z(vp: MultilinearZipParams, comms, points, evals, transcript: "PcsTranscript", field: "FieldConfig"):
+        """verify_z.rs:40-58"""
+        for c, pt, ev in zip(comms, points, evals):
+            MultilinearZip.verify(vp, c, pt, ev, field, transcript)
 
     @staticmethod
     def open(pp: MultilinearZipParams, evaluations, commit_data: MultilinearZipData, point: np.ndarray,
