@@ -306,3 +306,25 @@ def test_open_stream_pieces_concatenate_to_the_proof(cabi, num_vars, chunk):
     assert len(seen) == 2
     # the handle is still usable afterwards
     assert com.open(evals, cf, cols, q0, cabi.make_field(BENCH_MODULUS, 4)).tobytes() == proof_o.tobytes()
+
+
+def test_pipelined_gather_recovers_from_a_timed_out_wait(cabi, monkeypatch):
+    """The gather of a chunk is gated on a counter of the still running commit kernel; when that wait
+    gives up (kernel dispatch serialised by a profiler, say) the gather is redone after the commit."""
+    torch = pytest.importorskip("torch")
+    nv = 20  # 1024 rows: four pipeline chunks
+    z = orc.Zip(nv)
+    evals = _witness(nv, seed=4)
+    rows_o, layers_o, _ = z.commit(evals)
+    cols = np.array([0, 5, 2047, 1024, 77], dtype=np.uint32)
+    ctx = _ctx(cabi, z)
+    d = torch.from_numpy(evals).cuda()
+    want = ctx.commit(d)[0].open_columns(cols)
+    monkeypatch.setenv("ZIP_HIP_FORCE_WAIT_TIMEOUT", "1")
+    com, _ = ctx.commit(d)
+    got = com.open_columns(cols)  # enqueued right behind the commit: the waits give up after 1 ms
+    monkeypatch.delenv("ZIP_HIP_FORCE_WAIT_TIMEOUT")
+    assert np.array_equal(got, want)
+    per_col = z.num_rows * (32 + 8 + 32 * z.depth)
+    rows3 = rows_o.reshape(z.num_rows, z.codeword_len, 4)
+    assert got[per_col:per_col + z.num_rows * 32].tobytes() == rows3[:, 5, :].astype("<u8").tobytes()
