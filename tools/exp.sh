@@ -1,6 +1,11 @@
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_full_size.py -m gpu -x -q -k "large_codeword or 2pow26 or for_open or commit_bit_exact" 2>&1 | tail -3
-ZIP_HIP_OLD16=1 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_full_size.py -m gpu -x -q -k "large_codeword or 2pow26" 2>&1 | tail -2
-for i in 1 2; do
-echo "== new"; timeout -k 10 300 python tools/kernel_times.py --num-vars 26 --reps 3 --serial 2>&1 | grep -E "raa_commit|raa_encode"
-echo "== old"; ZIP_HIP_OLD16=1 timeout -k 10 300 python tools/kernel_times.py --num-vars 26 --reps 3 --serial 2>&1 | grep -E "raa_commit|raa_encode"
+#!/bin/bash
+# A/B driver for experiments on the GPU box:  gpurun -- 'bash tools/exp.sh > gpurun_out/exp.log 2>&1'
+# run <ENV=..>...  : one bench line (value, ms/step, per-kernel ms) under the given environment
+# Knobs: ZIP_HIP_CHUNKS=n (pipeline chunks), ZIP_HIP_COMBINE_LAST=1 (row combinations after the gather),
+#        ZIP_HIP_GATHER_PRIO=0|1, ZIP_HIP_NO_PRIORITY=1, ZIP_HIP_LIB_PATH=<other build of libzip_hip.so>
+run() { echo -n "$* : "; env "$@" timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline $EXTRA 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k:v for k,v in d['kernels_ms_per_step'].items() if 'wait' not in k})"; }
+for i in 1 2 3; do
+run ZIP_HIP_CHUNKS=4
+run ZIP_HIP_CHUNKS=4 ZIP_HIP_COMBINE_LAST=1
+run ZIP_HIP_CHUNKS=1 ZIP_HIP_COMBINE_LAST=1
 done
