@@ -1480,28 +1480,32 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
     si.bytes[2] = (size_t)n_cols * 4;
     unsigned char *sb;
     if ((rc = stage_small(ctx, si, small, &sb))) return rc;
-    // The two row combinations do not depend on the commitment: they run on their own stream
-    // beside the column openings (and beside a commit that is still in flight).
-    static const bool combine_last = getenv("ZIP_HIP_COMBINE_LAST") != nullptr;
+    // The two row combinations do not depend on the commitment.  Where to put them (ZIP_HIP_COMBINE):
+    //   last (default)  after the gathers, alone: 0.16 ms;
+    //   aux             on their own stream beside commit and gathers: hidden at best, but the multiply-bound
+    //                   kernel is starved there (1.3-1.6 ms) and slows the others -- 3-5 % worse on the step;
+    //   first           on the main stream ahead of the gathers: they then wait 1.3 ms for it (serial).
+    static const char *combine_env = getenv("ZIP_HIP_COMBINE");
+    static const int place = !combine_env ? 2 : !strcmp(combine_env, "aux") ? 1 : !strcmp(combine_env, "first") ? 0 : 2;
+    const int64_t *coeffs_dv = reinterpret_cast<const int64_t *>(sb + si.off[0]);
+    const uint64_t *q0_dv = reinterpret_cast<const uint64_t *>(sb + si.off[1]);
     hipEvent_t staged = take_dep_event(ctx), combined = take_dep_event(ctx);
     c->aux.push_back(staged);
     c->aux.push_back(combined);
-    if (!combine_last) {
+    if (place == 0) {
+        if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o))) return rc;
+    } else if (place == 1) {
         HIP_TRY(ctx, hipEventRecord(staged, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, staged, 0));
-        if ((rc = run_combine(ctx, evals_d, reinterpret_cast<const int64_t *>(sb + si.off[0]),
-                              reinterpret_cast<const uint64_t *>(sb + si.off[1]), &hf, !single, true, o, ctx->s_aux)))
-            return rc;
+        if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o, ctx->s_aux))) return rc;
         HIP_TRY(ctx, hipEventRecord(combined, ctx->s_aux));
     }
     if ((rc = run_open_columns_pipelined(c, reinterpret_cast<const uint32_t *>(sb + si.off[2]), n_cols,
                                          out_d + u_bytes)))
         return rc;
-    if (combine_last) {
-        if ((rc = run_combine(ctx, evals_d, reinterpret_cast<const int64_t *>(sb + si.off[0]),
-                              reinterpret_cast<const uint64_t *>(sb + si.off[1]), &hf, !single, true, o)))
-            return rc;
-    } else {
+    if (place == 2) {
+        if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o))) return rc;
+    } else if (place == 1) {
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, combined, 0));
     }
     // synchronises: the small host inputs (coeffs, cols, q0) have been consumed
