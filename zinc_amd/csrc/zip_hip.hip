@@ -1069,12 +1069,12 @@ int32_t zip_ctx_create(const zip_params *p, zip_ctx **out) {
         }
         *ctx->timeout_flag_h = 0;
         // pipeline chunks: the persistent commit kernel publishes its rows in this many groups
-        ctx->n_chunks = rows_local >= 1024 ? 4 : 1;
+        // (0 = chosen per commit from the number of rounds; ZIP_HIP_CHUNKS overrides)
+        ctx->n_chunks = 0;
         if (const char *env = getenv("ZIP_HIP_CHUNKS")) {
             const long v = strtol(env, nullptr, 10);
             if (v >= 1 && v <= 64) ctx->n_chunks = (uint32_t)v;
         }
-        if (ctx->n_chunks > rows_local) ctx->n_chunks = rows_local;
         const size_t pb = (size_t)p->codeword_len * 4;
         if (hipMalloc((void **)&ctx->perm1_d, pb) != hipSuccess || hipMalloc((void **)&ctx->perm2_d, pb) != hipSuccess) {
             rc = ZIP_ERR_ALLOC;
@@ -1175,7 +1175,9 @@ int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_k
         const uint32_t rounds = (R + G - 1) / G;
         // rows_per_chunk also batches the in-kernel upper tree levels, so keep it even without
         // chunk signalling (commit_no_merkle has neither)
-        uint32_t nch = with_merkle ? ctx->n_chunks : 1;
+        // default: chunks of four rounds (measured best at 2^22 / 2^23 / 2^24: 1 / 2 / 4 chunks) -- fewer
+        // rounds per chunk starve the batched upper levels, more leave the gather too little to overlap
+        uint32_t nch = !with_merkle ? 1 : ctx->n_chunks ? ctx->n_chunks : std::min(8u, std::max(1u, rounds / 4));
         if (nch > rounds) nch = rounds;
         const uint32_t rpc = (rounds + nch - 1) / nch;
         nch = (rounds + rpc - 1) / rpc;
