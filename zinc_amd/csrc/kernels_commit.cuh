@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(1024, 5) raa_commit_kernel(CommitArgs a) {
         }
         pidx[e] = v1 | (v2 << 16);
     }
-    // ... and the NEXT witness row, fetched while the current one is being hashed (rep = 2
+    // ... and the NEXT witness row, fetched during the scan passes of the current one (rep = 2
     // geometry: row_len == NPF * blockDim; anything else takes the direct path).
     constexpr int NPF = (E >= 2) ? E / 2 : 1;
     const bool prefetch = row_len == NPF * T;
@@ -340,10 +340,16 @@ __global__ void __launch_bounds__(1024, 5) raa_commit_kernel(CommitArgs a) {
         const int64_t *in = a.evals + (size_t)row * row_len;
         uint64_t *out_row = a.rows + (size_t)row * cw * 4;
 
+        const bool has_next = row + gridDim.x < a.num_rows;
         if (!(prefetch && round)) {
             if (round) lds_barrier();  // the previous row's LDS image has been consumed
             for (uint32_t i = tid; i < row_len; i += T) rowbuf[i] = in[i];
             lds_barrier();
+        }
+        if (prefetch && has_next) {  // the NEXT witness row: in flight during the two scan passes
+            const int64_t *nin = a.evals + (size_t)(row + gridDim.x) * row_len;
+#pragma unroll
+            for (int k = 0; k < NPF; k++) nxt[k] = nin[k * T + tid];
         }
 
         i128 v[E];
@@ -389,7 +395,6 @@ __global__ void __launch_bounds__(1024, 5) raa_commit_kernel(CommitArgs a) {
             for (int e = 0; e < E; e++) v[e] += pre;
         }
 
-        const bool has_next = row + gridDim.x < a.num_rows;
         // ---- transpose to strided ownership through LDS, then rows + hashes ------
         if (active) {
 #pragma unroll
@@ -399,12 +404,14 @@ __global__ void __launch_bounds__(1024, 5) raa_commit_kernel(CommitArgs a) {
                 t2hi[slot] = (uint32_t)((u128)v[e] >> 64);
             }
         }
-        lds_barrier();
-        if (prefetch && has_next) {  // in flight during the whole hash phase
-            const int64_t *nin = a.evals + (size_t)(row + gridDim.x) * row_len;
+        if (prefetch && has_next) {
+            // rowbuf was last read in pass 1 (two barriers ago): stage the prefetched row now, under the
+            // barrier below, so that NO barrier follows the hash phase -- the waves of a SIMD finish
+            // hashing one after the other, and the early ones go straight on into the next row's pass 1
 #pragma unroll
-            for (int k = 0; k < NPF; k++) nxt[k] = nin[k * T + tid];
+            for (int k = 0; k < NPF; k++) rowbuf[k * T + tid] = nxt[k];
         }
+        lds_barrier();
         ZIPK_PH(ph_a);
         if (active) {
             StridedLeaves<E> src;
@@ -434,13 +441,6 @@ __global__ void __launch_bounds__(1024, 5) raa_commit_kernel(CommitArgs a) {
         const bool last = row + gridDim.x >= a.num_rows;
         if (last || (round + 1) % a.rounds_per_chunk == 0) {
             finish_chunk<HASH>(a, LOGE + 1, round, tid, T);
-        }
-        if (prefetch && has_next) {
-            // rowbuf was last read in pass 1 and every lane has finished with the planes: stage the
-            // prefetched row for the next iteration (which then starts straight in pass 1)
-#pragma unroll
-            for (int k = 0; k < NPF; k++) rowbuf[k * T + tid] = nxt[k];
-            lds_barrier();
         }
         ZIPK_PH(ph_c);
     }
