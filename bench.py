@@ -263,7 +263,7 @@ def main():
                          "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(commit_bytes),
                          "note": "this kernel is int32-VALU bound, not HBM bound: 67.1M BLAKE3 compressions are "
                                  "7.7e8 wave-instructions, a 1.35 ms issue floor at the 2.2 GHz the chip holds "
-                                 "(DESIGN.md); while it runs, the column gather and row combinations overlap it"},
+                                 "(DESIGN.md); the column gather of finished chunks runs beside it, which stretches it from 1.45 ms alone"},
             "whole_path": {"algorithmic_bytes": int(sum(ab.values())),
                            "hbm_frac": round(sum(ab.values()) / step_s / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(ktimes.items())},
