@@ -125,6 +125,14 @@ int32_t zinc_sumcheck_prove_product(zinc_transcript *transcript, const uint64_t 
                                     uint32_t nvars, uint32_t degree, const uint64_t *modulus, uint32_t limbs,
                                     int32_t device, uint64_t *msgs_out, uint64_t *randomness_out);
 
+/* MLSumcheck::prove_as_subprotocol with sumcheck_polynomial_comb_fn_1 (src/zinc/utils.rs:77-94):
+ * (sum_t c[t] * prod_{j in S[t]} vals[j]) * vals[n_mles - 1].  c: n_terms field elements (Montgomery);
+ * s_masks[t]: the bits of ccs.S[t] as positions in `mles` (the eq() MLE is the last one). */
+int32_t zinc_sumcheck_prove_ccs(zinc_transcript *transcript, const uint64_t *const *mles, uint32_t n_mles,
+                                uint32_t nvars, uint32_t degree, uint32_t n_terms, const uint64_t *c,
+                                const uint32_t *s_masks, const uint64_t *modulus, uint32_t limbs, int32_t device,
+                                uint64_t *msgs_out, uint64_t *randomness_out);
+
 #ifdef __cplusplus
 }
 #endif

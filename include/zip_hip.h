@@ -200,9 +200,14 @@ int32_t zip_verify(zip_ctx *ctx, const uint8_t *roots, const uint8_t *proof, zip
                    const uint64_t *q1_mont, const uint64_t *eval_mont, const zip_field *field,
                    zip_verify_report *report);
 
-/* ---- sumcheck prover for a product of MLEs ---------------------
- * IPForMLSumcheck::prove_round (src/sumcheck/prover.rs:62-180) with comb_fn(vals) = vals[0] * vals[1] * ...
- * (ZincProver's second sumcheck, src/zinc/prover.rs:297-302), one call per round; the caller keeps the
+/* ---- sumcheck prover --------------------------------------------
+ * IPForMLSumcheck::prove_round (src/sumcheck/prover.rs:62-180) for the two combination functions
+ * ZincProver uses -- comb == NULL: comb_fn(vals) = vals[0] * vals[1] * ... (second sumcheck,
+ * src/zinc/prover.rs:297-302); comb != NULL: sumcheck_polynomial_comb_fn_1 (src/zinc/utils.rs:77-94),
+ *   (sum_t coeff[t] * prod_{j in term_mask[t]} vals[j]) * vals[n_mles - 1]
+ * with coeff = ccs.c (Montgomery limbs), term_mask[t] = the bits of ccs.S[t] (positions in the MLE list of
+ * prepare_lin_sumcheck_polynomial, zinc/utils.rs:49-75) and the eq() MLE last -- one call per round; the
+ * caller keeps the
  * transcript (MLSumcheck::prove_as_subprotocol, src/sumcheck.rs:56-112: absorb the evaluations, squeeze
  * the challenge, absorb it, hand it to the next round).
  *   mles      n_mles (1..4) tables of 2^num_vars field elements, Montgomery limbs, variable 0 = least
@@ -213,8 +218,14 @@ int32_t zip_verify(zip_ctx *ctx, const uint8_t *roots, const uint8_t *proof, zip
  *             with it (fix_variables, src/poly_f/mle/dense.rs:142-168) in the same pass
  *   evaluations_out  HOST, (degree + 1) * field->limbs limbs */
 typedef struct zip_sumcheck zip_sumcheck;
+typedef struct {
+    uint32_t n_terms;      /* 1..8 */
+    uint32_t term_mask[8]; /* bit j: MLE j is a factor of the term */
+    uint64_t coeff[8][8];  /* Montgomery limbs, little-endian, unused limbs zero */
+} zip_sumcheck_comb;
 int32_t zip_sumcheck_init(int32_t device, const uint64_t *const *mles, zip_mem_kind kind, uint32_t n_mles,
-                          uint32_t num_vars, uint32_t degree, const zip_field *field, zip_sumcheck **out);
+                          uint32_t num_vars, uint32_t degree, const zip_sumcheck_comb *comb, const zip_field *field,
+                          zip_sumcheck **out);
 int32_t zip_sumcheck_round(zip_sumcheck *s, const uint64_t *r_prev, uint64_t *evaluations_out);
 const char *zip_sumcheck_last_error(const zip_sumcheck *s);
 void zip_sumcheck_free(zip_sumcheck *s);

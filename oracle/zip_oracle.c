@@ -1211,10 +1211,31 @@ void orc_mle_eval_field(const orc_field *f, const uint64_t *evals, uint32_t eval
     free(eq);
 }
 
-/* ------------------------------------------------------------------ sumcheck prover (product) */
-int orc_sumcheck_prove_product(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint32_t nvars,
-                               uint32_t degree, orc_keccak *tr, uint64_t *msgs_out,
-                               uint64_t *randomness_out) {
+/* ------------------------------------------------------------------ sumcheck prover */
+/* comb_fn over the values of the MLEs at one point: the product of all of them (n_terms == 0,
+ * zinc/prover.rs:300) or sumcheck_polynomial_comb_fn_1 (zinc/utils.rs:77-94) */
+static void sc_comb(const orc_field *f, uint64_t (*vals)[ORC_MAX_FL], uint32_t n_mles, uint32_t n_terms,
+                    const uint32_t *term_masks, const uint64_t *coeffs, uint64_t *out) {
+    const uint32_t fl = f->fl;
+    if (n_terms == 0) {
+        memcpy(out, vals[0], 8 * fl);
+        for (uint32_t k = 1; k < n_mles; k++) orc_field_mul(f, out, vals[k]);
+        return;
+    }
+    uint64_t result[ORC_MAX_FL] = {0}, term[ORC_MAX_FL];
+    for (uint32_t t = 0; t < n_terms; t++) {
+        memcpy(term, coeffs + (size_t)t * fl, 8 * fl);
+        for (uint32_t j = 0; j < n_mles; j++)
+            if ((term_masks[t] >> j) & 1u) orc_field_mul(f, term, vals[j]);
+        orc_field_add(f, result, term);
+    }
+    orc_field_mul(f, result, vals[n_mles - 1]); /* eq() is the last MLE */
+    memcpy(out, result, 8 * fl);
+}
+
+int orc_sumcheck_prove(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint32_t nvars, uint32_t degree,
+                       uint32_t n_terms, const uint32_t *term_masks, const uint64_t *coeffs, orc_keccak *tr,
+                       uint64_t *msgs_out, uint64_t *randomness_out) {
     const uint32_t fl = f->fl;
     if (nvars == 0 || n_mles == 0 || n_mles > 8 || degree > 8) return ORC_ERR_PARAM;
     const size_t n = (size_t)1 << nvars;
@@ -1245,26 +1266,23 @@ int orc_sumcheck_prove_product(const orc_field *f, uint64_t *mles, uint32_t n_ml
         uint64_t evals[9][ORC_MAX_FL];
         memset(evals, 0, sizeof evals);
         for (size_t b = 0; b < half; b++) {
-            uint64_t v0[8][ORC_MAX_FL], vals[8][ORC_MAX_FL], step[8][ORC_MAX_FL], prod[ORC_MAX_FL];
+            uint64_t v0[8][ORC_MAX_FL], vals[8][ORC_MAX_FL], step[8][ORC_MAX_FL], c[ORC_MAX_FL];
             for (uint32_t k = 0; k < n_mles; k++)
                 memcpy(v0[k], mles + ((size_t)k * n + 2 * b) * fl, 8 * fl);
-            memcpy(prod, v0[0], 8 * fl);
-            for (uint32_t k = 1; k < n_mles; k++) orc_field_mul(f, prod, v0[k]);
-            orc_field_add(f, evals[0], prod);
+            sc_comb(f, v0, n_mles, n_terms, term_masks, coeffs, c);
+            orc_field_add(f, evals[0], c);
             if (degree > 0) {
                 for (uint32_t k = 0; k < n_mles; k++) {
                     memcpy(vals[k], mles + ((size_t)k * n + 2 * b + 1) * fl, 8 * fl);
                     memcpy(step[k], vals[k], 8 * fl);
                     orc_field_sub(f, step[k], v0[k]);
                 }
-                memcpy(prod, vals[0], 8 * fl);
-                for (uint32_t k = 1; k < n_mles; k++) orc_field_mul(f, prod, vals[k]);
-                orc_field_add(f, evals[1], prod);
+                sc_comb(f, vals, n_mles, n_terms, term_masks, coeffs, c);
+                orc_field_add(f, evals[1], c);
                 for (uint32_t e = 2; e <= degree; e++) {
                     for (uint32_t k = 0; k < n_mles; k++) orc_field_add(f, vals[k], step[k]);
-                    memcpy(prod, vals[0], 8 * fl);
-                    for (uint32_t k = 1; k < n_mles; k++) orc_field_mul(f, prod, vals[k]);
-                    orc_field_add(f, evals[e], prod);
+                    sc_comb(f, vals, n_mles, n_terms, term_masks, coeffs, c);
+                    orc_field_add(f, evals[e], c);
                 }
             }
         }
@@ -1278,4 +1296,10 @@ int orc_sumcheck_prove_product(const orc_field *f, uint64_t *mles, uint32_t n_ml
         orc_tr_absorb_field(tr, f, r);   /* sumcheck.rs:103 */
     }
     return ORC_OK;
+}
+
+int orc_sumcheck_prove_product(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint32_t nvars,
+                               uint32_t degree, orc_keccak *tr, uint64_t *msgs_out,
+                               uint64_t *randomness_out) {
+    return orc_sumcheck_prove(f, mles, n_mles, nvars, degree, 0, NULL, NULL, tr, msgs_out, randomness_out);
 }

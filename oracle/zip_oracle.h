@@ -189,6 +189,14 @@ void orc_mle_eval_field(const orc_field *f, const uint64_t *evals, uint32_t eval
 int orc_sumcheck_prove_product(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint32_t nvars,
                                uint32_t degree, orc_keccak *transcript, uint64_t *msgs_out,
                                uint64_t *randomness_out);
+/* The same with the combination function of ZincProver's first sumcheck
+ * (sumcheck_polynomial_comb_fn_1, src/zinc/utils.rs:77-94):
+ *   comb(vals) = (sum_t coeffs[t] * prod_{j in term_masks[t]} vals[j]) * vals[n_mles - 1]
+ * term_masks[t]: bit j set = MLE j is a factor of term t (ccs.S[t]); coeffs: n_terms field elements
+ * (ccs.c, Montgomery).  n_terms == 0 selects the plain product of all MLEs. */
+int orc_sumcheck_prove(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint32_t nvars, uint32_t degree,
+                       uint32_t n_terms, const uint32_t *term_masks, const uint64_t *coeffs,
+                       orc_keccak *transcript, uint64_t *msgs_out, uint64_t *randomness_out);
 
 int orc_num_threads(void);
 

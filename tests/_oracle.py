@@ -190,6 +190,22 @@ def sumcheck_prove_product(f: Field, mles: np.ndarray, degree: int, transcript: 
     return msgs, rand
 
 
+def sumcheck_prove(f: Field, mles: np.ndarray, degree: int, term_masks, coeffs_mont, transcript: Keccak):
+    """prove_as_subprotocol with comb = (sum_t coeffs[t] * prod_{j in mask t} vals[j]) * vals[-1]
+    (sumcheck_polynomial_comb_fn_1, zinc/utils.rs:77-94).  coeffs_mont: Python ints (Montgomery)."""
+    m = np.ascontiguousarray(mles, dtype=np.uint64).copy()
+    K, n, fl = m.shape
+    nv = n.bit_length() - 1
+    msgs = np.zeros((nv, degree + 1, fl), dtype=np.uint64)
+    rand = np.zeros((nv, fl), dtype=np.uint64)
+    masks = np.ascontiguousarray(term_masks, dtype=np.uint32)
+    cf = field_elems(list(coeffs_mont), fl)
+    rc = lib().orc_sumcheck_prove(C.byref(f), _u64p(m), K, nv, degree, masks.size, _u32p(masks), _u64p(cf),
+                                  C.byref(transcript), _u64p(msgs), _u64p(rand))
+    assert rc == 0, rc
+    return msgs, rand
+
+
 def build_eq_x_r(f: Field, r: np.ndarray) -> np.ndarray:
     nvars = r.shape[0]
     out = np.zeros((1 << nvars, f.fl), dtype=np.uint64)

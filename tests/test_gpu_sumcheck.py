@@ -97,3 +97,52 @@ def test_sumcheck_usage_errors(mods):
     sc.round()
     with pytest.raises(cabi.ZipError):
         sc.round()                         # "verifier message is empty" (prover.rs:87-89)
+
+
+@pytest.mark.parametrize("modulus,fl", [(BENCH_MODULUS, 4), (TEST_MODULUS_2, 2), (MOD_3LIMB, 3)])
+@pytest.mark.parametrize("nv", [1, 6, 11])
+def test_sumcheck_ccs_combination_equals_the_oracle(mods, modulus, fl, nv):
+    """ZincProver's first sumcheck (zinc/prover.rs:241-259): comb = (M0 * M1 - M2) * eq for an R1CS-shaped CCS
+    (c = [1, -1], S = [[0, 1], [2]]; sumcheck_polynomial_comb_fn_1, zinc/utils.rs:77-94), degree 3."""
+    cabi, pcs = mods
+    f = orc.make_field(modulus, fl)
+    mles = _tables(f, fl, modulus, 4, nv, seed=nv + 40)
+    R = 1 << (64 * fl)
+    c = [1 * R % modulus, (modulus - 1) * R % modulus]
+    S = [[0, 1], [2]]
+    to = orc.new_transcript()
+    orc.absorb(to, b"sumcheck-1")
+    msgs_o, rand_o = orc.sumcheck_prove(f, mles, 3, [0b011, 0b100], c, to)
+    t = pcs.KeccakTranscript()
+    t.absorb(b"sumcheck-1")
+    msgs, rand = pcs.sumcheck_prove_ccs(t, mles, 3, orc.field_elems(c, fl), S, pcs.FieldConfig(modulus, fl))
+    assert np.array_equal(msgs, msgs_o) and np.array_equal(rand, rand_o)
+    assert t.get_u64() == orc.lib().orc_tr_get_u64(orc.C.byref(to))
+
+
+def test_sumcheck_ccs_general_terms_and_zero_coefficients(mods):
+    """three terms over three MLEs + eq, one coefficient zero (skipped, zinc/utils.rs:80-82), degree 4"""
+    cabi, pcs = mods
+    modulus, fl, nv = BENCH_MODULUS, 4, 7
+    f = orc.make_field(modulus, fl)
+    mles = _tables(f, fl, modulus, 4, nv, seed=9)
+    R = 1 << (64 * fl)
+    c_std = [5, 0, modulus - 7]
+    c = [x * R % modulus for x in c_std]
+    S = [[0, 1, 2], [1], [0, 2]]
+    to = orc.new_transcript()
+    msgs_o, rand_o = orc.sumcheck_prove(f, mles, 4, [0b111, 0b101], [c[0], c[2]], to)
+    t = pcs.KeccakTranscript()
+    msgs, rand = pcs.sumcheck_prove_ccs(t, mles, 4, orc.field_elems(c, fl), S, pcs.FieldConfig(modulus, fl))
+    assert np.array_equal(msgs, msgs_o) and np.array_equal(rand, rand_o)
+    # device-resident tables through the ABI
+    torch = pytest.importorskip("torch")
+    dev = [torch.from_numpy(mles[k].view(np.int64)).cuda() for k in range(4)]
+    comb = cabi.make_comb([0b111, 0b101], orc.field_elems([c[0], c[2]], fl))
+    sc = cabi.Sumcheck(dev, nv, 4, cabi.make_field(modulus, fl), comb=comb)
+    r = None
+    for i in range(nv):
+        assert np.array_equal(sc.round(r), msgs_o[i]), i
+        r = rand_o[i]
+    with pytest.raises(cabi.ZipError):
+        cabi.Sumcheck(dev, nv, 4, cabi.make_field(modulus, fl), comb=cabi.make_comb([0b10000], orc.field_elems([c[0]], fl)))

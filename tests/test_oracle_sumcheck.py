@@ -72,3 +72,35 @@ def test_sumcheck_prover_identities(modulus, fl, K, degree, nv):
         ri = orc.get_challenge(replay, f)
         assert ri == orc.limbs_to_int(rand[i])
         orc.absorb_field(replay, f, ri)
+
+
+@pytest.mark.parametrize("modulus,fl", [(BENCH_MODULUS, 4), (TEST_MODULUS_2, 2)])
+@pytest.mark.parametrize("nv", [1, 4, 6])
+def test_sumcheck_prover_ccs_combination(modulus, fl, nv):
+    """comb = (c0 * M0 * M1 + c1 * M2) * eq  -- sumcheck_polynomial_comb_fn_1 for an R1CS-shaped CCS
+    (c = [1, -1], S = [[0, 1], [2]], zinc/utils.rs:49-94), degree d + 1 = 3."""
+    q = modulus
+    f = orc.make_field(q, fl)
+    rng = np.random.default_rng(nv)
+    n, K, degree = 1 << nv, 4, 3
+    std = [[int(rng.integers(0, 2**62)) * int(rng.integers(1, 2**62)) % q for _ in range(n)] for _ in range(K)]
+    R = 1 << (64 * fl)
+    mles = np.stack([orc.field_elems([v * R % q for v in t], fl) for t in std])
+    c = [1, q - 1]
+    masks = [0b011, 0b100]
+    tr = orc.new_transcript()
+    msgs, rand = orc.sumcheck_prove(f, mles, degree, masks, [x * R % q for x in c], tr)
+    g = [[_std(orc.limbs_to_int(msgs[i, e]), q, fl) for e in range(degree + 1)] for i in range(nv)]
+    r = [_std(orc.limbs_to_int(rand[i]), q, fl) for i in range(nv)]
+    comb = lambda v: (c[0] * v[0] * v[1] + c[1] * v[2]) * v[3] % q
+    claimed = sum(comb([t[b] for t in std]) for b in range(n)) % q
+    assert (g[0][0] + g[0][1]) % q == claimed
+    for i in range(1, nv):
+        assert (g[i][0] + g[i][1]) % q == _interp(g[i - 1], r[i - 1], q)
+    finals = []
+    for t in std:
+        cur = t[:]
+        for ri in r:
+            cur = [(cur[2 * b] + ri * (cur[2 * b + 1] - cur[2 * b])) % q for b in range(len(cur) // 2)]
+        finals.append(cur[0])
+    assert comb(finals) == _interp(g[-1], r[-1], q)

@@ -62,6 +62,23 @@ VERIFY_ACCEPT, VERIFY_PROXIMITY_TESTING, VERIFY_EVAL_CONSISTENCY, VERIFY_PROXIMI
 VERIFY_MERKLE, VERIFY_MALFORMED, VERIFY_OVERFLOW = 4, 5, 6
 
 
+class SumcheckComb(C.Structure):
+    """zip_sumcheck_comb: (sum_t coeff[t] * prod_{j in term_mask[t]} vals[j]) * vals[-1]"""
+    _fields_ = [("n_terms", C.c_uint32), ("term_mask", C.c_uint32 * 8), ("coeff", (C.c_uint64 * 8) * 8)]
+
+
+def make_comb(term_masks, coeffs_limbs):
+    """term_masks: ints; coeffs_limbs: [n_terms, limbs] Montgomery limbs"""
+    c = SumcheckComb()
+    c.n_terms = len(term_masks)
+    cl = np.asarray(coeffs_limbs, dtype=np.uint64).reshape(len(term_masks), -1)
+    for t, m in enumerate(term_masks):
+        c.term_mask[t] = int(m)
+        for i in range(cl.shape[1]):
+            c.coeff[t][i] = int(cl[t, i])
+    return c
+
+
 PROOF_SINK = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
@@ -109,7 +126,8 @@ def lib():
     L.zip_field_map_int256.argtypes = [vp, u64p, C.c_uint32, C.POINTER(ZipField), u64p]
     L.zip_open_stream.argtypes = [vp, i64p, C.c_int, i64p, u32p, C.c_uint32, u64p, C.POINTER(ZipField), PROOF_SINK,
                                   vp, C.c_size_t]
-    L.zip_sumcheck_init.argtypes = [C.c_int32, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(ZipField), C.POINTER(vp)]
+    L.zip_sumcheck_init.argtypes = [C.c_int32, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(SumcheckComb),
+                                    C.POINTER(ZipField), C.POINTER(vp)]
     L.zip_sumcheck_round.argtypes = [vp, u64p, u64p]
     L.zip_sumcheck_last_error.argtypes = [vp]
     L.zip_sumcheck_last_error.restype = C.c_char_p
@@ -430,10 +448,10 @@ def merkle_trees(leaves, depth, device=0):
 
 
 class Sumcheck:
-    """Device prover state of one product sumcheck (zip_sumcheck_*).  mles: list of CUDA int64/uint64 tensors
+    """Device prover state of one sumcheck (zip_sumcheck_*): product of the MLEs, or the CCS form `comb`.  mles: list of CUDA int64/uint64 tensors
     (read in place) or one numpy array [K, 2^nv, limbs] (copied)."""
 
-    def __init__(self, mles, num_vars, degree, field: ZipField, device=0):
+    def __init__(self, mles, num_vars, degree, field: ZipField, device=0, comb: "SumcheckComb" = None):
         self.field, self.degree = field, degree
         if isinstance(mles, np.ndarray):
             self._keep = np.ascontiguousarray(mles, dtype=np.uint64)
@@ -445,7 +463,8 @@ class Sumcheck:
             kind = MEM_DEVICE
         arr = (C.c_void_p * len(ptrs))(*ptrs)
         h = C.c_void_p()
-        rc = lib().zip_sumcheck_init(device, arr, kind, len(ptrs), num_vars, degree, C.byref(field), C.byref(h))
+        rc = lib().zip_sumcheck_init(device, arr, kind, len(ptrs), num_vars, degree,
+                                     C.byref(comb) if comb is not None else None, C.byref(field), C.byref(h))
         if rc != ZIP_OK:
             raise ZipError(rc, "zip_sumcheck_init", strerror(rc))
         self._h = h

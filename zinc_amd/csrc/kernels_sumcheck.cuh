@@ -1,8 +1,10 @@
-// Sumcheck prover rounds for a product of multilinear extensions.
+// Sumcheck prover rounds for the two combination functions ZincProver uses.
 //
 // Reference loops replaced:
-//   IPForMLSumcheck::prove_round          src/sumcheck/prover.rs:62-180  (comb_fn = product of the
-//                                         MLE values, ZincProver's second sumcheck, zinc/prover.rs:300)
+//   IPForMLSumcheck::prove_round          src/sumcheck/prover.rs:62-180 with comb_fn = product of the MLE
+//                                         values (second sumcheck, zinc/prover.rs:300) or the CCS form
+//                                         (sum_t c_t prod_{j in S_t} v_j) * v_last (first sumcheck,
+//                                         sumcheck_polynomial_comb_fn_1, zinc/utils.rs:77-94)
 //   DenseMultilinearExtension::fix_variables  src/poly_f/mle/dense.rs:142-168
 //
 // One pass per round: the fold with the previous challenge (fix_variables) is fused into the
@@ -46,19 +48,26 @@ __device__ __forceinline__ void fe_store(uint64_t *p, const uint64_t (&a)[FL]) {
     for (int i = 0; i < FL; i++) p[i] = a[i];
 }
 
+constexpr int kSumcheckMaxTerms = 8;
+
 template <int FL>
 struct SumcheckRoundArgs {
     const uint64_t *src[kSumcheckMaxMles];  // tables of this round's input (2*half entries, or 4*half when fold)
     uint64_t *dst[kSumcheckMaxMles];        // folded tables (2*half entries) when fold
     uint64_t r[FL];                         // previous round's challenge (Montgomery), when fold
-    uint32_t n_mles, degree, fold;
+    uint32_t degree, fold;
     uint64_t half;                          // number of hypercube points b of this round: 2^(nv - round)
     uint64_t *partials;                     // [gridDim.x][degree + 1][FL]
+    // combination function: n_terms == 0: the product of all MLE values; otherwise
+    //   (sum_t coeff[t] * prod_{j in term_mask[t]} vals[j]) * vals[K - 1]   (zinc/utils.rs:77-94)
+    uint32_t n_terms;
+    uint32_t term_mask[kSumcheckMaxTerms];
+    uint64_t coeff[kSumcheckMaxTerms][FL];
 };
 
-// DEG = degree of the round polynomial (evaluations at 0..DEG); a template parameter so that the
-// per-point accumulators live in registers.
-template <int FL, int DEG>
+// K = number of MLEs, DEG = degree of the round polynomial (evaluations at 0..DEG); template
+// parameters so that the per-MLE values and the per-point accumulators live in registers.
+template <int FL, int K, int DEG>
 __global__ void __launch_bounds__(256) sumcheck_round_kernel(SumcheckRoundArgs<FL> a, FieldDev<FL> f) {
     extern __shared__ __align__(16) unsigned char sc_smem[];
     uint64_t *red = reinterpret_cast<uint64_t *>(sc_smem);  // [256][DEG + 1][FL]
@@ -74,10 +83,10 @@ __global__ void __launch_bounds__(256) sumcheck_round_kernel(SumcheckRoundArgs<F
     for (int i = 0; i < FL; i++) rr[i] = a.r[i];
 
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + tid; b < a.half; b += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t prod[DEG + 1][FL];
-#pragma unroll 1
-        for (uint32_t k = 0; k < a.n_mles; k++) {
-            uint64_t v0[FL], v1[FL];
+        uint64_t val[K][FL], step[K][FL];  // the value of MLE k at t = 0 and its increment per unit of t
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            uint64_t v1[FL];
             if (a.fold) {  // fix_variables with the previous challenge: p'[j] = p[2j] + r (p[2j+1] - p[2j])
                 uint64_t l[FL], d[FL], t[FL];
                 const uint64_t *s = a.src[k] + (size_t)(4 * b) * FL;
@@ -87,7 +96,7 @@ __global__ void __launch_bounds__(256) sumcheck_round_kernel(SumcheckRoundArgs<F
                 mont_mul<FL>(d, rr, f, t);
                 fe_add<FL>(l, t, f);
 #pragma unroll
-                for (int i = 0; i < FL; i++) v0[i] = l[i];
+                for (int i = 0; i < FL; i++) val[k][i] = l[i];
                 fe_load<FL>(l, s + 2 * FL);
                 fe_load<FL>(d, s + 3 * FL);
                 fe_sub<FL>(d, l, f);
@@ -95,42 +104,59 @@ __global__ void __launch_bounds__(256) sumcheck_round_kernel(SumcheckRoundArgs<F
                 fe_add<FL>(l, t, f);
 #pragma unroll
                 for (int i = 0; i < FL; i++) v1[i] = l[i];
-                fe_store<FL>(a.dst[k] + (size_t)(2 * b) * FL, v0);
+                fe_store<FL>(a.dst[k] + (size_t)(2 * b) * FL, val[k]);
                 fe_store<FL>(a.dst[k] + (size_t)(2 * b + 1) * FL, v1);
             } else {
                 const uint64_t *s = a.src[k] + (size_t)(2 * b) * FL;
-                fe_load<FL>(v0, s);
+                fe_load<FL>(val[k], s);
                 fe_load<FL>(v1, s + FL);
             }
-            // the values of this MLE at t = 0, 1, 2, ..: v0, v1, v1 + step, .. (prover.rs:128-150)
-            uint64_t step[FL], val[FL];
 #pragma unroll
-            for (int i = 0; i < FL; i++) { step[i] = v1[i]; val[i] = v1[i]; }
-            fe_sub<FL>(step, v0, f);
-#pragma unroll
-            for (int e = 0; e <= DEG; e++) {
-                uint64_t cur[FL];
-                if (e == 0) {
-#pragma unroll
-                    for (int i = 0; i < FL; i++) cur[i] = v0[i];
-                } else {
-                    if (e >= 2) fe_add<FL>(val, step, f);
-#pragma unroll
-                    for (int i = 0; i < FL; i++) cur[i] = val[i];
-                }
-                if (k == 0) {
-#pragma unroll
-                    for (int i = 0; i < FL; i++) prod[e][i] = cur[i];
-                } else {
-                    uint64_t t[FL];
-                    mont_mul<FL>(prod[e], cur, f, t);
-#pragma unroll
-                    for (int i = 0; i < FL; i++) prod[e][i] = t[i];
-                }
-            }
+            for (int i = 0; i < FL; i++) step[k][i] = v1[i];
+            fe_sub<FL>(step[k], val[k], f);
         }
+        // the values at t = 0, 1, 2, ..: v0, v0 + step (= v1), v1 + step, ..  (prover.rs:128-150)
 #pragma unroll
-        for (int e = 0; e <= DEG; e++) fe_add<FL>(acc[e], prod[e], f);
+        for (int e = 0; e <= DEG; e++) {
+            if (e > 0) {
+#pragma unroll
+                for (int k = 0; k < K; k++) fe_add<FL>(val[k], step[k], f);
+            }
+            uint64_t c[FL];
+            if (a.n_terms == 0) {
+#pragma unroll
+                for (int i = 0; i < FL; i++) c[i] = val[0][i];
+#pragma unroll
+                for (int k = 1; k < K; k++) {
+                    uint64_t t[FL];
+                    mont_mul<FL>(c, val[k], f, t);
+#pragma unroll
+                    for (int i = 0; i < FL; i++) c[i] = t[i];
+                }
+            } else {
+                uint64_t sum[FL];
+#pragma unroll
+                for (int i = 0; i < FL; i++) sum[i] = 0;
+                for (uint32_t tt = 0; tt < a.n_terms; tt++) {
+                    uint64_t term[FL];
+#pragma unroll
+                    for (int i = 0; i < FL; i++) term[i] = a.coeff[tt][i];
+                    const uint32_t m = a.term_mask[tt];
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        if ((m >> k) & 1u) {  // wave-uniform
+                            uint64_t t[FL];
+                            mont_mul<FL>(term, val[k], f, t);
+#pragma unroll
+                            for (int i = 0; i < FL; i++) term[i] = t[i];
+                        }
+                    }
+                    fe_add<FL>(sum, term, f);
+                }
+                mont_mul<FL>(sum, val[K - 1], f, c);  // eq() is the last MLE
+            }
+            fe_add<FL>(acc[e], c, f);
+        }
     }
     // block sum
 #pragma unroll

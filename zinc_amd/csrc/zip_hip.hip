@@ -109,6 +109,8 @@ struct zip_sumcheck {
     uint64_t *partials = nullptr, *evals_d = nullptr;
     uint32_t max_blocks = 0;
     uint64_t modulus[8] = {};
+    uint32_t n_terms = 0, term_mask[8] = {};  // zip_sumcheck_comb, or n_terms == 0 for the plain product
+    uint64_t coeff[8][8] = {};
 };
 
 namespace {
@@ -922,13 +924,13 @@ int32_t run_verify_fl(zip_ctx *ctx, const VerifyIn &in, const HostField &hf, std
 
 // ---- sumcheck prover -----------------------------------------
 namespace {
-template <int FL, int DEG>
+template <int FL, int K, int DEG>
 int32_t launch_sumcheck_round(zip_sumcheck *s, const SumcheckRoundArgs<FL> &a, uint32_t blocks, const FieldDev<FL> &fd) {
     zip_ctx *ctx = s->ctx;
     const size_t lds = (size_t)256 * (DEG + 1) * FL * 8;
     {
         LaunchTimer t(ctx, "sumcheck_round_kernel");
-        hipLaunchKernelGGL((sumcheck_round_kernel<FL, DEG>), dim3(blocks), dim3(256), lds, ctx->stream, a, fd);
+        hipLaunchKernelGGL((sumcheck_round_kernel<FL, K, DEG>), dim3(blocks), dim3(256), lds, ctx->stream, a, fd);
         HIP_TRY(ctx, hipGetLastError());
     }
     {
@@ -940,15 +942,29 @@ int32_t launch_sumcheck_round(zip_sumcheck *s, const SumcheckRoundArgs<FL> &a, u
     return ZIP_OK;
 }
 
+template <int FL, int K>
+int32_t sumcheck_round_k(zip_sumcheck *s, const SumcheckRoundArgs<FL> &a, uint32_t blocks, const FieldDev<FL> &fd) {
+    switch (s->degree) {
+        case 1: return launch_sumcheck_round<FL, K, 1>(s, a, blocks, fd);
+        case 2: return launch_sumcheck_round<FL, K, 2>(s, a, blocks, fd);
+        case 3: return launch_sumcheck_round<FL, K, 3>(s, a, blocks, fd);
+        default: return launch_sumcheck_round<FL, K, 4>(s, a, blocks, fd);
+    }
+}
+
 template <int FL>
 int32_t sumcheck_round_fl(zip_sumcheck *s, const uint64_t *r_prev, const HostField &hf) {
     SumcheckRoundArgs<FL> a{};
     const uint32_t round = s->round + 1;  // 1-based
-    a.n_mles = s->n_mles;
     a.degree = s->degree;
     a.half = (uint64_t)1 << (s->num_vars - round);
     a.fold = round > 1;
     a.partials = s->partials;
+    a.n_terms = s->n_terms;
+    for (uint32_t t = 0; t < s->n_terms; t++) {
+        a.term_mask[t] = s->term_mask[t];
+        for (int i = 0; i < FL; i++) a.coeff[t][i] = s->coeff[t][i];
+    }
     for (uint32_t k = 0; k < s->n_mles; k++) {
         // round 1 reads the input; round 2 folds input -> buf[0]; round j >= 3 folds buf[j & 1] ... alternating
         if (round == 1) a.src[k] = s->input[k];
@@ -960,11 +976,11 @@ int32_t sumcheck_round_fl(zip_sumcheck *s, const uint64_t *r_prev, const HostFie
     uint64_t want = (a.half + 255) / 256;
     uint32_t blocks = (uint32_t)std::min<uint64_t>(want ? want : 1, s->max_blocks);
     const FieldDev<FL> fd = to_dev<FL>(hf);
-    switch (s->degree) {
-        case 1: return launch_sumcheck_round<FL, 1>(s, a, blocks, fd);
-        case 2: return launch_sumcheck_round<FL, 2>(s, a, blocks, fd);
-        case 3: return launch_sumcheck_round<FL, 3>(s, a, blocks, fd);
-        default: return launch_sumcheck_round<FL, 4>(s, a, blocks, fd);
+    switch (s->n_mles) {
+        case 1: return sumcheck_round_k<FL, 1>(s, a, blocks, fd);
+        case 2: return sumcheck_round_k<FL, 2>(s, a, blocks, fd);
+        case 3: return sumcheck_round_k<FL, 3>(s, a, blocks, fd);
+        default: return sumcheck_round_k<FL, 4>(s, a, blocks, fd);
     }
 }
 }  // namespace
@@ -1772,9 +1788,11 @@ int32_t zip_open_stream(zip_commitment *c, const int64_t *evals, zip_mem_kind ev
 }
 
 int32_t zip_sumcheck_init(int32_t device, const uint64_t *const *mles, zip_mem_kind kind, uint32_t n_mles,
-                          uint32_t num_vars, uint32_t degree, const zip_field *field, zip_sumcheck **out) {
+                          uint32_t num_vars, uint32_t degree, const zip_sumcheck_comb *comb, const zip_field *field,
+                          zip_sumcheck **out) {
     if (!mles || !out || !field) return ZIP_ERR_NULL;
     *out = nullptr;
+    if (comb && (comb->n_terms < 1 || comb->n_terms > 8)) return ZIP_ERR_INVALID_PARAM;
     if (n_mles < 1 || n_mles > (uint32_t)kSumcheckMaxMles || degree < 1 || degree > (uint32_t)kSumcheckMaxDegree ||
         num_vars < 1 || num_vars > 30)
         return ZIP_ERR_INVALID_PARAM;  // nvars == 0: "Attempt to prove a constant." (prover.rs:47-49)
@@ -1796,6 +1814,15 @@ int32_t zip_sumcheck_init(int32_t device, const uint64_t *const *mles, zip_mem_k
         s->degree = degree;
         s->fl = hf.fl;
         memcpy(s->modulus, hf.modulus, sizeof s->modulus);
+        if (comb) {
+            s->n_terms = comb->n_terms;
+            for (uint32_t t = 0; t < comb->n_terms; t++) {
+                if (comb->term_mask[t] >> n_mles) { rc = fail(ctx, ZIP_ERR_INVALID_PARAM, "term %u refers to an MLE that does not exist", t); break; }
+                s->term_mask[t] = comb->term_mask[t];
+                memcpy(s->coeff[t], comb->coeff[t], sizeof s->coeff[t]);
+            }
+            if (rc) break;
+        }
         const size_t n = (size_t)1 << num_vars, elem = (size_t)hf.fl * 8;
         for (uint32_t k = 0; k < n_mles && rc == ZIP_OK; k++) {
             if (!mles[k]) { rc = ZIP_ERR_NULL; break; }

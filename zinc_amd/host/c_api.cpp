@@ -295,4 +295,29 @@ int32_t zinc_sumcheck_prove_product(zinc_transcript *transcript, const uint64_t 
     });
 }
 
+int32_t zinc_sumcheck_prove_ccs(zinc_transcript *transcript, const uint64_t *const *mles, uint32_t n_mles,
+                                uint32_t nvars, uint32_t degree, uint32_t n_terms, const uint64_t *c,
+                                const uint32_t *s_masks, const uint64_t *modulus, uint32_t limbs, int32_t device,
+                                uint64_t *msgs_out, uint64_t *randomness_out) {
+    if (!transcript || !mles || !c || !s_masks || !msgs_out || !randomness_out) return ZINC_ERR_NULL;
+    return guarded([&] {
+        const FieldConfig f = FieldConfig::make(modulus, limbs);
+        std::vector<const uint64_t *> tables(mles, mles + n_mles);
+        std::vector<Limbs> cv(n_terms);
+        std::vector<std::vector<uint32_t>> S(n_terms);
+        for (uint32_t t = 0; t < n_terms; t++) {
+            cv[t] = load(c + (size_t)t * limbs, limbs);
+            for (uint32_t j = 0; j < 32; j++)
+                if ((s_masks[t] >> j) & 1u) S[t].push_back(j);
+        }
+        const auto res = zinc::sumcheck::prove_as_subprotocol_ccs(transcript->t, tables, nvars, degree, cv, S, f, device);
+        for (size_t r = 0; r < res.proof.msgs.size(); r++) {
+            for (uint32_t e = 0; e <= degree; e++)
+                for (uint32_t i = 0; i < limbs; i++)
+                    msgs_out[(r * (degree + 1) + e) * limbs + i] = res.proof.msgs[r][e][i];
+            for (uint32_t i = 0; i < limbs; i++) randomness_out[r * limbs + i] = res.randomness[r][i];
+        }
+    });
+}
+
 }  // extern "C"

@@ -788,17 +788,18 @@ zip::ZipProof zip::commit_z_mle_and_prove_evaluation(const LinearCodeSpec &lc_sp
     return out;
 }
 
-sumcheck::ProverOutput sumcheck::prove_as_subprotocol_product(KeccakTranscript &transcript,
-                                                              const std::vector<const uint64_t *> &mles, uint32_t nvars,
-                                                              uint32_t degree, const FieldConfig &config, int device) {
+namespace {
+sumcheck::ProverOutput prove_as_subprotocol_impl(KeccakTranscript &transcript, const std::vector<const uint64_t *> &mles,
+                                                 uint32_t nvars, uint32_t degree, const zip_sumcheck_comb *comb,
+                                                 const FieldConfig &config, int device) {
     // sumcheck.rs:64-76 (FIELD_LIMBS > 1: the u128 map)
     transcript.absorb_random_field(config, map_to_field_u128(config, nvars, 0));
     transcript.absorb_random_field(config, map_to_field_u128(config, degree, 0));
-    ProverOutput out;
+    sumcheck::ProverOutput out;
     if (nvars == 0) return out;  // :77-92: empty proof
     const zip_field zf = config.to_abi();
     zip_sumcheck *raw = nullptr;
-    int32_t rc = zip_sumcheck_init(device, mles.data(), ZIP_MEM_HOST, (uint32_t)mles.size(), nvars, degree, &zf, &raw);
+    int32_t rc = zip_sumcheck_init(device, mles.data(), ZIP_MEM_HOST, (uint32_t)mles.size(), nvars, degree, comb, &zf, &raw);
     if (rc) throw ZipError(rc == ZIP_ERR_INVALID_PARAM ? ZipError::InvalidPcsParam : ZipError::Device,
                            std::string("zip_sumcheck_init: ") + zip_strerror(rc));
     std::unique_ptr<zip_sumcheck, void (*)(zip_sumcheck *)> s(raw, zip_sumcheck_free);
@@ -818,6 +819,36 @@ sumcheck::ProverOutput sumcheck::prove_as_subprotocol_product(KeccakTranscript &
         out.randomness.push_back(r);
     }
     return out;
+}
+}  // namespace
+
+sumcheck::ProverOutput sumcheck::prove_as_subprotocol_product(KeccakTranscript &transcript,
+                                                              const std::vector<const uint64_t *> &mles, uint32_t nvars,
+                                                              uint32_t degree, const FieldConfig &config, int device) {
+    return prove_as_subprotocol_impl(transcript, mles, nvars, degree, nullptr, config, device);
+}
+
+sumcheck::ProverOutput sumcheck::prove_as_subprotocol_ccs(KeccakTranscript &transcript,
+                                                          const std::vector<const uint64_t *> &mles, uint32_t nvars,
+                                                          uint32_t degree, const std::vector<Limbs> &c,
+                                                          const std::vector<std::vector<uint32_t>> &S,
+                                                          const FieldConfig &config, int device) {
+    if (c.size() != S.size()) throw std::logic_error("ccs.c and ccs.S differ in length");
+    zip_sumcheck_comb comb{};
+    for (size_t t = 0; t < c.size(); t++) {
+        bool zero = true;  // terms with a zero coefficient are skipped (zinc/utils.rs:80-82)
+        for (uint32_t i = 0; i < config.limbs; i++) zero &= c[t][i] == 0;
+        if (zero) continue;
+        if (comb.n_terms == 8) throw ZipError(ZipError::InvalidPcsParam, "more than 8 non-zero CCS terms");
+        for (uint32_t j : S[t]) {
+            if (j >= mles.size()) throw std::logic_error("index out of bounds: ccs.S refers to a missing MLE");
+            comb.term_mask[comb.n_terms] |= 1u << j;
+        }
+        for (uint32_t i = 0; i < config.limbs; i++) comb.coeff[comb.n_terms][i] = c[t][i];
+        comb.n_terms++;
+    }
+    if (comb.n_terms == 0) throw ZipError(ZipError::InvalidPcsParam, "no non-zero CCS term");
+    return prove_as_subprotocol_impl(transcript, mles, nvars, degree, &comb, config, device);
 }
 
 }  // namespace zinc

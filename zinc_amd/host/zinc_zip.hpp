@@ -261,5 +261,12 @@ struct ProverOutput {
 // mles[k]: 2^nvars field elements as flat little-endian Montgomery limbs (config.limbs each), host memory.
 ProverOutput prove_as_subprotocol_product(KeccakTranscript &transcript, const std::vector<const uint64_t *> &mles,
                                           uint32_t nvars, uint32_t degree, const FieldConfig &config, int device = 0);
+// The same with sumcheck_polynomial_comb_fn_1 (src/zinc/utils.rs:77-94; ZincProver::sumcheck_1,
+// zinc/prover.rs:241-259): (sum_t c[t] * prod_{j in S[t]} vals[j]) * vals.last().  c: ccs.c (Montgomery),
+// S: ccs.S as positions in `mles`, whose last entry is the eq() MLE (prepare_lin_sumcheck_polynomial).
+ProverOutput prove_as_subprotocol_ccs(KeccakTranscript &transcript, const std::vector<const uint64_t *> &mles,
+                                      uint32_t nvars, uint32_t degree, const std::vector<Limbs> &c,
+                                      const std::vector<std::vector<uint32_t>> &S, const FieldConfig &config,
+                                      int device = 0);
 }  // namespace sumcheck
 }  // namespace zinc

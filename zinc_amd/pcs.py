@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "zinc_pcs_transcript_free", "zinc_pcs_transcript_len", "zinc_pcs_transcript_copy",
     "zinc_pcs_transcript_probe", "zinc_zip_open", "zinc_pcs_transcript_from_proof", "zinc_pcs_transcript_position",
     "zinc_zip_verify", "zinc_zip_evaluate", "zinc_commit_z_mle_and_prove_evaluation", "zinc_zip_proof_len",
-    "zinc_zip_proof_num_roots", "zinc_zip_proof_read", "zinc_zip_proof_free", "zinc_zip_release_cached_contexts", "zinc_sumcheck_prove_product", "zinc_zip_data_download", "zinc_zip_data_upload", "zinc_merkle_tree_new",
+    "zinc_zip_proof_num_roots", "zinc_zip_proof_read", "zinc_zip_proof_free", "zinc_zip_release_cached_contexts", "zinc_sumcheck_prove_product", "zinc_sumcheck_prove_ccs", "zinc_zip_data_download", "zinc_zip_data_upload", "zinc_merkle_tree_new",
 )
 
 
@@ -100,6 +100,8 @@ def lib():
         L.zinc_zip_proof_read.argtypes = [vp, vp, vp, vp]
         L.zinc_zip_proof_read.restype = None
         L.zinc_zip_proof_free.argtypes = [vp]
+        L.zinc_sumcheck_prove_ccs.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp,
+                                              C.c_uint32, C.c_int32, vp, vp]
         L.zinc_zip_data_download.argtypes = [vp, vp, vp, vp]
         L.zinc_zip_data_upload.argtypes = [vp, vp, vp, vp, C.POINTER(vp)]
         L.zinc_merkle_tree_new.argtypes = [C.c_uint32, vp, C.c_size_t, C.c_uint32, C.c_int32, vp]
@@ -404,4 +406,20 @@ def sumcheck_prove_product(transcript: KeccakTranscript, mles, degree: int, fiel
     rand = np.zeros((nv, fl), np.uint64)
     _check(lib().zinc_sumcheck_prove_product(transcript._h, ptrs, K, nv, degree, field._m.ctypes.data, fl, device,
                                              msgs.ctypes.data, rand.ctypes.data))
+    return msgs, rand
+
+
+def sumcheck_prove_ccs(transcript: KeccakTranscript, mles, degree: int, c, S, field: FieldConfig, device: int = 0):
+    """prove_as_subprotocol with sumcheck_polynomial_comb_fn_1 (zinc/utils.rs:77-94): c = ccs.c as [n_terms, limbs]
+    Montgomery limbs, S = ccs.S (lists of positions in `mles`, the eq() MLE last)."""
+    m = np.ascontiguousarray(mles, dtype=np.uint64)
+    K, n, fl = m.shape
+    nv = n.bit_length() - 1
+    ptrs = (C.c_void_p * K)(*[m[k].ctypes.data for k in range(K)])
+    cv = np.ascontiguousarray(c, dtype=np.uint64).reshape(len(S), fl)
+    masks = np.array([sum(1 << j for j in s) for s in S], dtype=np.uint32)
+    msgs = np.zeros((nv, degree + 1, fl), np.uint64)
+    rand = np.zeros((nv, fl), np.uint64)
+    _check(lib().zinc_sumcheck_prove_ccs(transcript._h, ptrs, K, nv, degree, len(S), cv.ctypes.data, masks.ctypes.data,
+                                         field._m.ctypes.data, fl, device, msgs.ctypes.data, rand.ctypes.data))
     return msgs, rand
