@@ -331,3 +331,27 @@ def test_pipelined_gather_recovers_from_a_timed_out_wait(cabi, monkeypatch):
     for r in (0, 511, 512, 2047):
         rc, enc = z.encode_row(evals[r * z.row_len:(r + 1) * z.row_len])
         assert rc == 0 and vals[r].tobytes() == enc[5].astype("<u8").tobytes(), r
+
+
+def test_open_and_verify_on_the_2pow26_geometry(cabi):
+    """cw = 16384, depth 14 (raa_commit16_kernel's trees): the whole proof against the oracle, then the
+    device verifier, on a 16-row slice of the geometry."""
+    z = orc.Zip(17, geometry=(8192, 16, 16384))
+    f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    evals = _witness(17, seed=12)
+    point = orc.point_to_field(f, np.arange(3, 20, dtype=np.int64))
+    rows_o, layers_o, roots_o = z.commit(evals)
+    proof_o, cols, coeffs = z.open(f, evals, rows_o, layers_o, point, orc.new_transcript())
+    ctx = _ctx(cabi, z)
+    com, roots = ctx.commit(evals)
+    assert np.array_equal(roots, roots_o)
+    lr = 4  # log2(16 rows)
+    q0 = orc.build_eq_x_r(f, point[17 - lr:])
+    q1 = orc.build_eq_x_r(f, point[: 17 - lr])
+    proof = com.open(evals, coeffs, cols, q0, zf)
+    assert np.array_equal(proof, proof_o)
+    ev = z.mle_eval(f, evals, point)
+    assert z.verify(f, roots, point, ev, proof) == 0
+    rep = ctx.verify(roots, proof, coeffs, cols, q0, q1, np.array(orc.int_to_limbs(ev, 4), dtype=np.uint64), zf)
+    assert rep["verdict"] == cabi.VERIFY_ACCEPT and rep["bad_merkle_paths"] == 0
