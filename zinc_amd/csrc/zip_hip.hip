@@ -1499,12 +1499,16 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
     unsigned char *sb;
     if ((rc = stage_small(ctx, si, small, &sb))) return rc;
     // The two row combinations do not depend on the commitment.  Where to put them (ZIP_HIP_COMBINE):
-    //   last (default)  after the gathers, alone: 0.16 ms;
-    //   aux             on their own stream beside commit and gathers: hidden at best, but the multiply-bound
-    //                   kernel is starved there (1.3-1.6 ms) and slows the others -- 3-5 % worse on the step;
+    //   tail (default)  on their own stream, held back until the commit kernel has ended: the multiply-bound
+    //                   kernel then runs beside the gather of the last chunk (memory-bound, nothing left to
+    //                   hash); 2.27 ms per step against 2.33 for `last`, and steadier;
+    //   last            after the gathers, alone: 0.16 ms;
+    //   aux             on their own stream from the start, beside commit and gathers: starved there
+    //                   (1.3-1.6 ms) and slows the others -- 3-5 % worse on the step;
     //   first           on the main stream ahead of the gathers: they then wait 1.3 ms for it (serial).
     static const char *combine_env = getenv("ZIP_HIP_COMBINE");
-    static const int place = !combine_env ? 2 : !strcmp(combine_env, "aux") ? 1 : !strcmp(combine_env, "first") ? 0 : 2;
+    static const int place = !combine_env ? 3 : !strcmp(combine_env, "aux") ? 1 : !strcmp(combine_env, "first") ? 0 :
+                             !strcmp(combine_env, "last") ? 2 : 3;
     const int64_t *coeffs_dv = reinterpret_cast<const int64_t *>(sb + si.off[0]);
     const uint64_t *q0_dv = reinterpret_cast<const uint64_t *>(sb + si.off[1]);
     hipEvent_t staged = take_dep_event(ctx), combined = take_dep_event(ctx);
@@ -1512,9 +1516,12 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
     c->aux.push_back(combined);
     if (place == 0) {
         if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o))) return rc;
-    } else if (place == 1) {
+    } else if (place == 1 || place == 3) {
         HIP_TRY(ctx, hipEventRecord(staged, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, staged, 0));
+        // tail: held back until the commit kernel has ended, so that it runs beside the gather of the LAST
+        // chunk (memory-bound, nothing left to hash) instead of beside the commit
+        if (place == 3 && c->done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, c->done, 0));
         if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o, ctx->s_aux))) return rc;
         HIP_TRY(ctx, hipEventRecord(combined, ctx->s_aux));
     }
@@ -1523,7 +1530,7 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
         return rc;
     if (place == 2) {
         if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o))) return rc;
-    } else if (place == 1) {
+    } else if (place == 1 || place == 3) {
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, combined, 0));
     }
     // synchronises: the small host inputs (coeffs, cols, q0) have been consumed
