@@ -1303,3 +1303,325 @@ int orc_sumcheck_prove_product(const orc_field *f, uint64_t *mles, uint32_t n_ml
                                uint64_t *randomness_out) {
     return orc_sumcheck_prove(f, mles, n_mles, nvars, degree, 0, NULL, NULL, tr, msgs_out, randomness_out);
 }
+
+/* ==================================================================================================
+ * Spartan prover / verifier of ZincProver (src/zinc/prover.rs, src/zinc/verifier.rs), CPU restatement.
+ * Test infrastructure like everything in this file.
+ * ================================================================================================== */
+
+/* Field inverse by Fermat (q prime).  The reference's Div goes through its own inverse; the result is the
+ * unique inverse either way. */
+void orc_field_inv(const orc_field *f, const uint64_t *a, uint64_t *out) {
+    uint64_t e[ORC_MAX_FL], two[ORC_MAX_FL] = {2}, acc[ORC_MAX_FL], base[ORC_MAX_FL];
+    memcpy(e, f->modulus, 8 * f->fl);
+    ul_sub(e, two, f->fl); /* q - 2 */
+    memcpy(acc, f->r, 8 * f->fl); /* one */
+    memcpy(base, a, 8 * f->fl);
+    for (uint32_t i = 0; i < 64 * f->fl; i++) {
+        if ((e[i / 64] >> (i % 64)) & 1) orc_field_mul(f, acc, base);
+        uint64_t sq[ORC_MAX_FL];
+        memcpy(sq, base, 8 * f->fl);
+        orc_field_mul(f, base, sq);
+    }
+    memcpy(out, acc, 8 * f->fl);
+}
+
+/* interpolate_uni_poly (src/sumcheck/verifier.rs:161-303): the value at x of the unique polynomial of
+ * degree < len through (i, p_i[i]), i = 0..len-1.  Same early returns for x in {0..len-1}; the general
+ * case is the same Lagrange sum (the reference only organises the denominators to save divisions). */
+void orc_interpolate_uni_poly(const orc_field *f, const uint64_t *p_i, uint32_t len, const uint64_t *x,
+                              uint64_t *out) {
+    const uint32_t fl = f->fl;
+    uint64_t j[ORC_MAX_FL] = {0}, evals[33][ORC_MAX_FL], prod[ORC_MAX_FL];
+    memcpy(prod, x, 8 * fl);
+    memcpy(evals[0], x, 8 * fl);
+    for (uint32_t i = 1; i < len; i++) { /* :176-185 */
+        if (!memcmp(x, j, 8 * fl)) {
+            memcpy(out, p_i + (size_t)(i - 1) * fl, 8 * fl);
+            return;
+        }
+        orc_field_add(f, j, f->r);
+        memcpy(evals[i], x, 8 * fl);
+        orc_field_sub(f, evals[i], j);
+        orc_field_mul(f, prod, evals[i]);
+    }
+    if (!memcmp(x, j, 8 * fl)) { /* :187-189 */
+        memcpy(out, p_i + (size_t)(len - 1) * fl, 8 * fl);
+        return;
+    }
+    uint64_t res[ORC_MAX_FL] = {0};
+    for (uint32_t i = 0; i < len; i++) {
+        /* denom_i = prod_{k != i} (i - k) as a field element */
+        uint64_t den[ORC_MAX_FL], t[ORC_MAX_FL];
+        memcpy(den, f->r, 8 * fl);
+        for (uint32_t k = 0; k < len; k++) {
+            if (k == i) continue;
+            orc_field_from_i64(f, (int64_t)i - (int64_t)k, t);
+            orc_field_mul(f, den, t);
+        }
+        orc_field_mul(f, den, evals[i]); /* denom_i * (x - i) */
+        orc_field_inv(f, den, t);
+        orc_field_mul(f, t, prod);
+        orc_field_mul(f, t, p_i + (size_t)i * fl);
+        orc_field_add(f, res, t);
+    }
+    memcpy(out, res, 8 * fl);
+}
+
+/* MLSumcheck::verify_as_subprotocol (src/sumcheck.rs:116-160) with verify_round and
+ * check_and_generate_subclaim (src/sumcheck/verifier.rs:61-143).  msgs: nvars * (degree + 1) elements.
+ * Returns ORC_OK and (point, expected_evaluation), or ORC_ERR_PROOF for SumCheckFailed. */
+int orc_sumcheck_verify(const orc_field *f, uint32_t nvars, uint32_t degree, const uint64_t *claimed_sum,
+                        const uint64_t *msgs, orc_keccak *tr, uint64_t *point_out, uint64_t *expected_out) {
+    const uint32_t fl = f->fl;
+    if (degree + 1 > 33) return ORC_ERR_PARAM;
+    uint64_t t[ORC_MAX_FL];
+    orc_field_from_u128(f, nvars, 0, t);
+    orc_tr_absorb_field(tr, f, t);
+    orc_field_from_u128(f, degree, 0, t);
+    orc_tr_absorb_field(tr, f, t);
+    if (nvars == 0) { /* :138-144 */
+        orc_tr_absorb_field(tr, f, claimed_sum);
+        memcpy(expected_out, claimed_sum, 8 * fl);
+        return ORC_OK;
+    }
+    for (uint32_t i = 0; i < nvars; i++) { /* :155-160 */
+        for (uint32_t e = 0; e <= degree; e++)
+            orc_tr_absorb_field(tr, f, msgs + ((size_t)i * (degree + 1) + e) * fl);
+        uint64_t *r = point_out + (size_t)i * fl;
+        orc_tr_get_challenge(tr, f, r);
+        orc_tr_absorb_field(tr, f, r);
+    }
+    uint64_t expected[ORC_MAX_FL];
+    memcpy(expected, claimed_sum, 8 * fl);
+    for (uint32_t i = 0; i < nvars; i++) { /* verifier.rs:110-137 */
+        const uint64_t *ev = msgs + (size_t)i * (degree + 1) * fl;
+        uint64_t s[ORC_MAX_FL];
+        memcpy(s, ev, 8 * fl);
+        if (degree > 0) orc_field_add(f, s, ev + fl);
+        if (memcmp(s, expected, 8 * fl)) return ORC_ERR_PROOF;
+        orc_interpolate_uni_poly(f, ev, degree + 1, point_out + (size_t)i * fl, expected);
+    }
+    memcpy(expected_out, expected, 8 * fl);
+    return ORC_OK;
+}
+
+/* the shape ZincProver's own code supports (see the header): square, power-of-two, MLE list == matrices */
+static int ccs_check(const orc_ccs *c) {
+    if (!c || !c->M || !c->S_masks || !c->c || c->t < 1 || c->t > 7 || c->q < 1 || c->q > 8) return ORC_ERR_PARAM;
+    if (c->s != c->s_prime || c->s < 1 || c->s > 28) return ORC_ERR_PARAM;
+    if (c->m != (1u << c->s) || c->n != c->m) return ORC_ERR_PARAM;
+    uint32_t pos = 0;
+    for (uint32_t i = 0; i < c->q; i++) { /* prepare_lin_sumcheck_polynomial pushes S[i]'s MLEs in order */
+        if (c->c[i] == 0) return ORC_ERR_PARAM;
+        for (uint32_t j = 0; j < c->t; j++)
+            if ((c->S_masks[i] >> j) & 1) {
+                if (j != pos) return ORC_ERR_PARAM;
+                pos++;
+            }
+    }
+    if (pos != c->t) return ORC_ERR_PARAM;
+    for (uint32_t k = 0; k < c->t; k++)
+        if (c->M[k].n_rows > c->m || c->M[k].n_cols != c->n) return ORC_ERR_PARAM;
+    return ORC_OK;
+}
+
+/* mat_vec_mul (src/ccs/utils.rs:47-76) after SparseMatrix::map_to_field (src/sparse_matrix.rs:38-58),
+ * padded to 2^s like DenseMultilinearExtension::from_evaluations_vec */
+static void ccs_mz(const orc_field *f, const orc_sparse *M, const uint64_t *z_f, uint32_t m, uint64_t *out) {
+    const uint32_t fl = f->fl;
+    memset(out, 0, (size_t)m * fl * 8);
+    for (uint32_t row = 0; row < M->n_rows; row++) {
+        uint64_t acc[ORC_MAX_FL] = {0};
+        for (uint32_t e = M->row_ptr[row]; e < M->row_ptr[row + 1]; e++) {
+            uint64_t v[ORC_MAX_FL], p[ORC_MAX_FL];
+            orc_field_from_i64(f, M->values[e], v);
+            memcpy(p, z_f + (size_t)M->col_idx[e] * fl, 8 * fl);
+            orc_field_mul(f, p, v);
+            orc_field_add(f, acc, p);
+        }
+        memcpy(out + (size_t)row * fl, acc, 8 * fl);
+    }
+}
+
+int orc_ccs_mz(const orc_field *f, const orc_ccs *ccs, const int64_t *z, uint32_t z_len, uint64_t *mz_out) {
+    int rc = ccs_check(ccs);
+    if (rc) return rc;
+    if (z_len > ccs->m) return ORC_ERR_PARAM;
+    const uint32_t fl = f->fl, m = ccs->m;
+    uint64_t *z_f = calloc((size_t)m * fl, 8);
+    if (!z_f) return ORC_ERR_ALLOC;
+    for (uint32_t i = 0; i < z_len; i++) orc_field_from_i64(f, z[i], z_f + (size_t)i * fl);
+    for (uint32_t k = 0; k < ccs->t; k++) ccs_mz(f, &ccs->M[k], z_f, m, mz_out + (size_t)k * m * fl);
+    free(z_f);
+    return ORC_OK;
+}
+
+/* sum_k gamma^k * compute_eval_table_sparse(M_k, eq_rx) (src/sparse_matrix.rs:165-182; the fold of
+ * src/zinc/prover.rs:279-290) */
+int orc_ccs_second_table(const orc_field *f, const orc_ccs *ccs, const uint64_t *eq_rx, const uint64_t *gamma,
+                         uint64_t *out) {
+    int rc = ccs_check(ccs);
+    if (rc) return rc;
+    const uint32_t fl = f->fl, m = ccs->m;
+    uint64_t *tab = calloc((size_t)m * fl, 8);
+    if (!tab) return ORC_ERR_ALLOC;
+    memset(out, 0, (size_t)m * fl * 8);
+    for (int32_t k = (int32_t)ccs->t - 1; k >= 0; k--) { /* .rev().fold: lin = lin * gamma + table_k */
+        const orc_sparse *M = &ccs->M[k];
+        memset(tab, 0, (size_t)m * fl * 8);
+        for (uint32_t row = 0; row < M->n_rows; row++)
+            for (uint32_t e = M->row_ptr[row]; e < M->row_ptr[row + 1]; e++) {
+                uint64_t v[ORC_MAX_FL], p[ORC_MAX_FL];
+                orc_field_from_i64(f, M->values[e], v);
+                memcpy(p, eq_rx + (size_t)row * fl, 8 * fl);
+                orc_field_mul(f, p, v);
+                orc_field_add(f, tab + (size_t)M->col_idx[e] * fl, p);
+            }
+        for (uint32_t i = 0; i < m; i++) {
+            orc_field_mul(f, out + (size_t)i * fl, gamma);
+            orc_field_add(f, out + (size_t)i * fl, tab + (size_t)i * fl);
+        }
+    }
+    free(tab);
+    return ORC_OK;
+}
+
+static void dot_field(const orc_field *f, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out) {
+    uint64_t acc[ORC_MAX_FL] = {0};
+    for (size_t i = 0; i < n; i++) {
+        uint64_t p[ORC_MAX_FL];
+        memcpy(p, a + i * f->fl, 8 * f->fl);
+        orc_field_mul(f, p, b + i * f->fl);
+        orc_field_add(f, acc, p);
+    }
+    memcpy(out, acc, 8 * f->fl);
+}
+
+/* SpartanProver::prove (src/zinc/prover.rs:130-161) after prepare_for_random_field_piop (:172-239).
+ *   z: x || 1 || w (Statement_Z::get_z_vector), z_len <= m; zero-extended to m (:230-232)
+ * Outputs: msgs1 s*(d+2) elements, r_x s, msgs2 s*3, r_y s, V_s t. */
+int orc_spartan_prove(const orc_field *f, const orc_ccs *ccs, const int64_t *z, uint32_t z_len, orc_keccak *tr,
+                      uint64_t *msgs1, uint64_t *r_x, uint64_t *msgs2, uint64_t *r_y, uint64_t *V_s) {
+    int rc = ccs_check(ccs);
+    if (rc) return rc;
+    if (z_len > ccs->m) return ORC_ERR_PARAM;
+    const uint32_t fl = f->fl, m = ccs->m, s = ccs->s, t = ccs->t;
+    const size_t tab = (size_t)m * fl;
+    uint64_t *mz = calloc(tab * t, 8), *g = calloc(tab * (t + 1), 8), *eq = calloc(tab, 8), *two = calloc(tab * 2, 8);
+    uint64_t *coeffs = calloc((size_t)ccs->q * fl, 8), *beta = calloc((size_t)s * fl, 8);
+    rc = ORC_ERR_ALLOC;
+    if (!mz || !g || !eq || !two || !coeffs || !beta) goto done;
+    /* sumcheck_1 (:242-259): beta (zinc/utils.rs:100-106), Mz MLEs, g = [Mz.., eq(beta)], degree d + 1 */
+    orc_keccak_update(tr, (const uint8_t *)"beta_s", 6);
+    for (uint32_t i = 0; i < s; i++) orc_tr_get_challenge(tr, f, beta + (size_t)i * fl);
+    if ((rc = orc_ccs_mz(f, ccs, z, z_len, mz))) goto done;
+    memcpy(g, mz, tab * t * 8);
+    if ((rc = orc_build_eq_x_r(f, beta, s, g + tab * t))) goto done;
+    for (uint32_t i = 0; i < ccs->q; i++) orc_field_from_i64(f, ccs->c[i], coeffs + (size_t)i * fl);
+    if ((rc = orc_sumcheck_prove(f, g, t + 1, s, ccs->d + 1, ccs->q, ccs->S_masks, coeffs, tr, msgs1, r_x))) goto done;
+    /* sumcheck_2 (:261-303) */
+    uint64_t gamma[ORC_MAX_FL];
+    orc_keccak_update(tr, (const uint8_t *)"gamma", 5);
+    orc_tr_get_challenge(tr, f, gamma);
+    if ((rc = orc_build_eq_x_r(f, r_x, s, eq))) goto done;
+    if ((rc = orc_ccs_second_table(f, ccs, eq, gamma, two))) goto done;
+    for (uint32_t i = 0; i < m; i++) /* z_mle.map_to_field (:149) */
+        if (i < z_len) orc_field_from_i64(f, z[i], two + tab + (size_t)i * fl);
+    if ((rc = orc_sumcheck_prove(f, two, 2, s, 2, 0, NULL, NULL, tr, msgs2, r_y))) goto done;
+    /* calculate_V_s (:330-347): Mz_k evaluated at r_x */
+    for (uint32_t k = 0; k < t; k++) dot_field(f, mz + tab * k, eq, m, V_s + (size_t)k * fl);
+    rc = ORC_OK;
+done:
+    free(mz); free(g); free(eq); free(two); free(coeffs); free(beta);
+    return rc;
+}
+
+/* lin_comb_V_s (src/zinc/verifier.rs:212-219) */
+static void lin_comb(const orc_field *f, const uint64_t *gamma, const uint64_t *v, uint32_t n, uint64_t *out) {
+    uint64_t res[ORC_MAX_FL] = {0};
+    for (int32_t i = (int32_t)n - 1; i >= 0; i--) {
+        orc_field_mul(f, res, gamma);
+        orc_field_add(f, res, v + (size_t)i * f->fl);
+    }
+    memcpy(out, res, 8 * f->fl);
+}
+
+/* SpartanVerifier::verify (src/zinc/verifier.rs:105-139).  Returns ORC_OK with the verification points
+ * (r_x, r_y, e_y, gamma) or ORC_ERR_PROOF. */
+int orc_spartan_verify(const orc_field *f, const orc_ccs *ccs, const uint64_t *msgs1, const uint64_t *msgs2,
+                       const uint64_t *V_s, orc_keccak *tr, uint64_t *r_x, uint64_t *r_y, uint64_t *e_y,
+                       uint64_t *gamma) {
+    int rc = ccs_check(ccs);
+    if (rc) return rc;
+    const uint32_t fl = f->fl, s = ccs->s;
+    uint64_t beta[32][ORC_MAX_FL], zero[ORC_MAX_FL] = {0}, sv[ORC_MAX_FL];
+    orc_keccak_update(tr, (const uint8_t *)"beta_s", 6);
+    for (uint32_t i = 0; i < s; i++) orc_tr_get_challenge(tr, f, beta[i]);
+    if ((rc = orc_sumcheck_verify(f, s, ccs->d + 1, zero, msgs1, tr, r_x, sv))) return rc; /* :142-162 */
+    /* verify_linearization_claim (:164-187) */
+    uint64_t e[ORC_MAX_FL], sum[ORC_MAX_FL] = {0};
+    memcpy(e, f->r, 8 * fl);
+    for (uint32_t i = 0; i < s; i++) { /* eq_eval, sumcheck/utils.rs:81-95 */
+        uint64_t xy[ORC_MAX_FL], term[ORC_MAX_FL];
+        memcpy(xy, r_x + (size_t)i * fl, 8 * fl);
+        orc_field_mul(f, xy, beta[i]);
+        memcpy(term, xy, 8 * fl);
+        orc_field_add(f, term, xy);
+        orc_field_sub(f, term, r_x + (size_t)i * fl);
+        orc_field_sub(f, term, beta[i]);
+        orc_field_add(f, term, f->r);
+        orc_field_mul(f, e, term);
+    }
+    for (uint32_t i = 0; i < ccs->q; i++) {
+        uint64_t term[ORC_MAX_FL];
+        orc_field_from_i64(f, ccs->c[i], term);
+        for (uint32_t j = 0; j < ccs->t; j++)
+            if ((ccs->S_masks[i] >> j) & 1) orc_field_mul(f, term, V_s + (size_t)j * fl);
+        orc_field_add(f, sum, term);
+    }
+    orc_field_mul(f, e, sum);
+    if (memcmp(e, sv, 8 * fl)) return ORC_ERR_PROOF;
+    orc_keccak_update(tr, (const uint8_t *)"gamma", 5);
+    orc_tr_get_challenge(tr, f, gamma);
+    uint64_t claimed[ORC_MAX_FL];
+    lin_comb(f, gamma, V_s, ccs->t, claimed);
+    return orc_sumcheck_verify(f, ccs->s_prime, 2, claimed, msgs2, tr, r_y, e_y); /* :189-210 */
+}
+
+/* The final check of verify_pcs_proof (src/zinc/verifier.rs:248-269):
+ *   lin_comb(gamma, [mle(M_k)(r_x, r_y)]_k) * v == e_y,
+ * with DenseMultilinearExtension::from_matrix (src/poly_f/mle/dense.rs:69-87: index = rows * col + row, so the
+ * low s variables select the row) evaluated as sum val * eq(r_x)[row] * eq(r_y)[col]. */
+int orc_spartan_final_check(const orc_field *f, const orc_ccs *ccs, const uint64_t *r_x, const uint64_t *r_y,
+                            const uint64_t *gamma, const uint64_t *v, const uint64_t *e_y) {
+    int rc = ccs_check(ccs);
+    if (rc) return rc;
+    const uint32_t fl = f->fl, m = ccs->m;
+    uint64_t *ex = calloc((size_t)m * fl, 8), *ey = calloc((size_t)m * fl, 8);
+    uint64_t vxy[8][ORC_MAX_FL];
+    if (!ex || !ey) { free(ex); free(ey); return ORC_ERR_ALLOC; }
+    orc_build_eq_x_r(f, r_x, ccs->s, ex);
+    orc_build_eq_x_r(f, r_y, ccs->s_prime, ey);
+    for (uint32_t k = 0; k < ccs->t; k++) {
+        const orc_sparse *M = &ccs->M[k];
+        uint64_t acc[ORC_MAX_FL] = {0};
+        for (uint32_t row = 0; row < M->n_rows; row++)
+            for (uint32_t e = M->row_ptr[row]; e < M->row_ptr[row + 1]; e++) {
+                uint64_t p[ORC_MAX_FL];
+                orc_field_from_i64(f, M->values[e], p);
+                orc_field_mul(f, p, ex + (size_t)row * fl);
+                orc_field_mul(f, p, ey + (size_t)M->col_idx[e] * fl);
+                orc_field_add(f, acc, p);
+            }
+        memcpy(vxy[k], acc, 8 * fl);
+    }
+    free(ex); free(ey);
+    uint64_t lhs[ORC_MAX_FL] = {0}; /* lin_comb_V_s over V_xy */
+    for (int32_t i = (int32_t)ccs->t - 1; i >= 0; i--) {
+        orc_field_mul(f, lhs, gamma);
+        orc_field_add(f, lhs, vxy[i]);
+    }
+    orc_field_mul(f, lhs, v);
+    return memcmp(lhs, e_y, 8 * fl) ? ORC_ERR_PROOF : ORC_OK;
+}

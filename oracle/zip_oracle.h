@@ -46,6 +46,7 @@ extern "C" {
 #define ORC_ERR_PARAM (-2)
 #define ORC_ERR_PROOF (-3)      /* verifier rejected */
 #define ORC_ERR_TRANSCRIPT (-4) /* proof stream exhausted */
+#define ORC_ERR_ALLOC (-5)
 
 #define ORC_MAX_FL 8 /* max field limbs handled */
 
@@ -197,6 +198,42 @@ int orc_sumcheck_prove_product(const orc_field *f, uint64_t *mles, uint32_t n_ml
 int orc_sumcheck_prove(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint32_t nvars, uint32_t degree,
                        uint32_t n_terms, const uint32_t *term_masks, const uint64_t *coeffs,
                        orc_keccak *transcript, uint64_t *msgs_out, uint64_t *randomness_out);
+
+/* ---------------------------------------------------------------- Spartan (ZincProver / ZincVerifier) */
+/* SparseMatrix<Int<1>> (src/sparse_matrix.rs:12-17) flattened to CSR: row_ptr has n_rows + 1 entries;
+ * rows the reference's `coeffs` does not hold (pad_rows only bumps n_rows) are simply empty. */
+typedef struct {
+    uint32_t n_rows, n_cols;
+    const uint32_t *row_ptr, *col_idx;
+    const int64_t *values;
+} orc_sparse;
+/* CCS_Z (src/ccs/ccs_z.rs:30-52) + Statement_Z.constraints.  S_masks[i]: bit j set = matrix j in S[i].
+ * Supported shape = what ZincProver itself supports: m == n == 2^s == 2^s_prime (compute_eval_table_sparse
+ * asserts rx.len() == ccs.n, ccs_f.rs:133, sparse_matrix.rs:172), every c[i] != 0 and the concatenation of
+ * the S[i] equal to 0..t-1 in order (sumcheck_polynomial_comb_fn_1 indexes the MLE list of
+ * prepare_lin_sumcheck_polynomial by matrix number, zinc/utils.rs:66-70,84-88). */
+typedef struct {
+    uint32_t m, n, s, s_prime, t, q, d;
+    const orc_sparse *M;
+    const uint32_t *S_masks;
+    const int64_t *c;
+} orc_ccs;
+
+void orc_field_inv(const orc_field *f, const uint64_t *a, uint64_t *out);
+void orc_interpolate_uni_poly(const orc_field *f, const uint64_t *p_i, uint32_t len, const uint64_t *x,
+                              uint64_t *out);                                   /* sumcheck/verifier.rs:161-303 */
+int orc_sumcheck_verify(const orc_field *f, uint32_t nvars, uint32_t degree, const uint64_t *claimed_sum,
+                        const uint64_t *msgs, orc_keccak *tr, uint64_t *point_out, uint64_t *expected_out);
+int orc_ccs_mz(const orc_field *f, const orc_ccs *ccs, const int64_t *z, uint32_t z_len, uint64_t *mz_out);
+int orc_ccs_second_table(const orc_field *f, const orc_ccs *ccs, const uint64_t *eq_rx, const uint64_t *gamma,
+                         uint64_t *out);
+int orc_spartan_prove(const orc_field *f, const orc_ccs *ccs, const int64_t *z, uint32_t z_len, orc_keccak *tr,
+                      uint64_t *msgs1, uint64_t *r_x, uint64_t *msgs2, uint64_t *r_y, uint64_t *V_s);
+int orc_spartan_verify(const orc_field *f, const orc_ccs *ccs, const uint64_t *msgs1, const uint64_t *msgs2,
+                       const uint64_t *V_s, orc_keccak *tr, uint64_t *r_x, uint64_t *r_y, uint64_t *e_y,
+                       uint64_t *gamma);
+int orc_spartan_final_check(const orc_field *f, const orc_ccs *ccs, const uint64_t *r_x, const uint64_t *r_y,
+                            const uint64_t *gamma, const uint64_t *v, const uint64_t *e_y);
 
 int orc_num_threads(void);
 

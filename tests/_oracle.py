@@ -14,7 +14,7 @@ ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 _LIB_PATH = os.path.join(ORACLE_DIR, "_build", "libzip_oracle.so")
 
 ORC_MAX_FL = 8
-ORC_OK, ORC_ERR_OVERFLOW, ORC_ERR_PARAM, ORC_ERR_PROOF, ORC_ERR_TRANSCRIPT = 0, -1, -2, -3, -4
+ORC_OK, ORC_ERR_OVERFLOW, ORC_ERR_PARAM, ORC_ERR_PROOF, ORC_ERR_TRANSCRIPT, ORC_ERR_ALLOC = 0, -1, -2, -3, -4, -5
 
 
 class Keccak(C.Structure):
@@ -204,6 +204,102 @@ def sumcheck_prove(f: Field, mles: np.ndarray, degree: int, term_masks, coeffs_m
                                   C.byref(transcript), _u64p(msgs), _u64p(rand))
     assert rc == 0, rc
     return msgs, rand
+
+
+class Sparse(C.Structure):
+    _fields_ = [("n_rows", C.c_uint32), ("n_cols", C.c_uint32), ("row_ptr", C.POINTER(C.c_uint32)),
+                ("col_idx", C.POINTER(C.c_uint32)), ("values", C.POINTER(C.c_int64))]
+
+
+class CcsStruct(C.Structure):
+    _fields_ = [("m", C.c_uint32), ("n", C.c_uint32), ("s", C.c_uint32), ("s_prime", C.c_uint32),
+                ("t", C.c_uint32), ("q", C.c_uint32), ("d", C.c_uint32), ("M", C.POINTER(Sparse)),
+                ("S_masks", C.POINTER(C.c_uint32)), ("c", C.POINTER(C.c_int64))]
+
+
+class Ccs:
+    """orc_ccs over a tests/_ccs.CcsInstance (keeps the numpy arrays alive)."""
+
+    def __init__(self, inst):
+        self.inst = inst
+        self._mats = (Sparse * inst.t)()
+        for k, m in enumerate(inst.matrices):
+            self._mats[k] = Sparse(m.n_rows, m.n_cols, _u32p(m.row_ptr), _u32p(m.col_idx),
+                                   m.values.ctypes.data_as(C.POINTER(C.c_int64)))
+        self._masks = inst.masks
+        self._c = np.array(inst.c, dtype=np.int64)
+        self.struct = CcsStruct(inst.m, inst.n, inst.s, inst.s_prime, inst.t, inst.q, inst.d, self._mats,
+                                _u32p(self._masks), self._c.ctypes.data_as(C.POINTER(C.c_int64)))
+
+    def _z(self):
+        z = self.inst.z
+        return z.ctypes.data_as(C.POINTER(C.c_int64)), len(z)
+
+    def mz(self, f: Field) -> np.ndarray:
+        out = np.zeros((self.inst.t, self.inst.m, f.fl), dtype=np.uint64)
+        zp, zl = self._z()
+        rc = lib().orc_ccs_mz(C.byref(f), C.byref(self.struct), zp, zl, _u64p(out))
+        assert rc == 0, rc
+        return out
+
+    def second_table(self, f: Field, eq_rx: np.ndarray, gamma: np.ndarray) -> np.ndarray:
+        out = np.zeros((self.inst.m, f.fl), dtype=np.uint64)
+        rc = lib().orc_ccs_second_table(C.byref(f), C.byref(self.struct), _u64p(np.ascontiguousarray(eq_rx)),
+                                        _u64p(np.ascontiguousarray(gamma)), _u64p(out))
+        assert rc == 0, rc
+        return out
+
+    def spartan_prove(self, f: Field, transcript: Keccak):
+        """SpartanProver::prove.  Returns dict(msgs1, r_x, msgs2, r_y, V_s) of uint64 limb arrays."""
+        i, fl = self.inst, f.fl
+        out = dict(msgs1=np.zeros((i.s, i.d + 2, fl), dtype=np.uint64), r_x=np.zeros((i.s, fl), dtype=np.uint64),
+                   msgs2=np.zeros((i.s, 3, fl), dtype=np.uint64), r_y=np.zeros((i.s, fl), dtype=np.uint64),
+                   V_s=np.zeros((i.t, fl), dtype=np.uint64))
+        zp, zl = self._z()
+        rc = lib().orc_spartan_prove(C.byref(f), C.byref(self.struct), zp, zl, C.byref(transcript), _u64p(out["msgs1"]),
+                                     _u64p(out["r_x"]), _u64p(out["msgs2"]), _u64p(out["r_y"]), _u64p(out["V_s"]))
+        assert rc == 0, rc
+        return out
+
+    def spartan_verify(self, f: Field, proof, transcript: Keccak):
+        """SpartanVerifier::verify.  Returns (rc, dict(r_x, r_y, e_y, gamma))."""
+        i, fl = self.inst, f.fl
+        pts = dict(r_x=np.zeros((i.s, fl), dtype=np.uint64), r_y=np.zeros((i.s_prime, fl), dtype=np.uint64),
+                   e_y=np.zeros(fl, dtype=np.uint64), gamma=np.zeros(fl, dtype=np.uint64))
+        rc = lib().orc_spartan_verify(C.byref(f), C.byref(self.struct), _u64p(np.ascontiguousarray(proof["msgs1"])),
+                                      _u64p(np.ascontiguousarray(proof["msgs2"])), _u64p(np.ascontiguousarray(proof["V_s"])),
+                                      C.byref(transcript), _u64p(pts["r_x"]), _u64p(pts["r_y"]), _u64p(pts["e_y"]),
+                                      _u64p(pts["gamma"]))
+        return rc, pts
+
+    def final_check(self, f: Field, pts, v: np.ndarray) -> int:
+        return lib().orc_spartan_final_check(C.byref(f), C.byref(self.struct), _u64p(pts["r_x"]), _u64p(pts["r_y"]),
+                                             _u64p(pts["gamma"]), _u64p(np.ascontiguousarray(v)), _u64p(pts["e_y"]))
+
+
+def field_inv(f: Field, a_mont: int) -> int:
+    a = (C.c_uint64 * ORC_MAX_FL)(*int_to_limbs(a_mont, f.fl))
+    out = (C.c_uint64 * ORC_MAX_FL)()
+    lib().orc_field_inv(C.byref(f), a, out)
+    return limbs_to_int(out[: f.fl])
+
+
+def interpolate_uni_poly(f: Field, p_mont, x_mont: int) -> int:
+    p = field_elems(list(p_mont), f.fl)
+    x = (C.c_uint64 * ORC_MAX_FL)(*int_to_limbs(x_mont, f.fl))
+    out = (C.c_uint64 * ORC_MAX_FL)()
+    lib().orc_interpolate_uni_poly(C.byref(f), _u64p(p), len(p_mont), x, out)
+    return limbs_to_int(out[: f.fl])
+
+
+def sumcheck_verify(f: Field, nvars, degree, claimed_mont: int, msgs: np.ndarray, transcript: Keccak):
+    """verify_as_subprotocol.  Returns (rc, point [nvars, fl], expected_evaluation int (Montgomery))."""
+    point = np.zeros((max(nvars, 1), f.fl), dtype=np.uint64)
+    exp = (C.c_uint64 * ORC_MAX_FL)()
+    cl = (C.c_uint64 * ORC_MAX_FL)(*int_to_limbs(claimed_mont, f.fl))
+    rc = lib().orc_sumcheck_verify(C.byref(f), nvars, degree, cl, _u64p(np.ascontiguousarray(msgs)), C.byref(transcript),
+                                   _u64p(point), exp)
+    return rc, point[:nvars], limbs_to_int(exp[: f.fl])
 
 
 def build_eq_x_r(f: Field, r: np.ndarray) -> np.ndarray:
