@@ -13,6 +13,8 @@
 #define ZINC_ZIP_HOST_H
 #include <stddef.h>
 #include <stdint.h>
+
+#include "zip_hip.h" /* zip_sparse_matrix */
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -132,6 +134,20 @@ int32_t zinc_sumcheck_prove_ccs(zinc_transcript *transcript, const uint64_t *con
                                 uint32_t nvars, uint32_t degree, uint32_t n_terms, const uint64_t *c,
                                 const uint32_t *s_masks, const uint64_t *modulus, uint32_t limbs, int32_t device,
                                 uint64_t *msgs_out, uint64_t *randomness_out);
+
+/* ZincProver (src/zinc/prover.rs): Prover::prove (:50-88) when with_pcs != 0, else
+ * prepare_for_random_field_piop + SpartanProver::prove (:130-161, what benches/spartan_benches.rs times).
+ *   constraints   Statement_Z.constraints as CSR (zip_sparse_matrix, include/zip_hip.h), t matrices of
+ *                 2^s columns; CCS_Z {m = n = 2^s, s = s_prime = s, d, S = s_masks (bit j: matrix j), c}
+ *   public_input / w_ccs   Statement_Z.public_input (l entries), Witness_Z.w_ccs: z = x || 1 || w
+ *   outputs       SpartanProof.linearization_sumcheck: s * (d + 2) elements; .second_sumcheck: s * 3;
+ *                 .V_s: t; r_y: s elements (all Montgomery limbs); ZipProof through the last argument when with_pcs != 0
+ * ZINC_ERR_PANIC where the reference panics (shapes the prover's own assertions reject). */
+int32_t zinc_prover_prove(const zip_sparse_matrix *constraints, uint32_t t, uint32_t s, uint32_t d, uint32_t q,
+                          const uint32_t *s_masks, const int64_t *c, const int64_t *public_input, size_t l,
+                          const int64_t *w_ccs, size_t w_len, zinc_transcript *transcript, const uint64_t *modulus,
+                          uint32_t limbs, int32_t device, int32_t with_pcs, uint64_t *msgs1_out, uint64_t *msgs2_out,
+                          uint64_t *v_s_out, uint64_t *r_y_out, zinc_zip_proof **zip_proof_out);
 
 #ifdef __cplusplus
 }

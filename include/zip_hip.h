@@ -230,6 +230,44 @@ int32_t zip_sumcheck_round(zip_sumcheck *s, const uint64_t *r_prev, uint64_t *ev
 const char *zip_sumcheck_last_error(const zip_sumcheck *s);
 void zip_sumcheck_free(zip_sumcheck *s);
 
+/* ---- the field loops of SpartanProver::prove around its sumchecks (BASELINE configs[4]) ---------
+ * A zip_ccs holds the constraint matrices of a CCS (Statement_Z.constraints, src/ccs/ccs_z.rs:155-158,
+ * mapped to F_q as SparseMatrix::map_to_field does, src/sparse_matrix.rs:38-58) and the per-proof
+ * tables in HBM.  With zip_sumcheck_* (tables handed over as ZIP_MEM_DEVICE) this is everything
+ * src/zinc/prover.rs:130-161 computes; the caller keeps the transcript.
+ *   zip_sparse_matrix   SparseMatrix<Int<1>> as CSR: row_ptr[n_rows + 1], col_idx / values[row_ptr[n_rows]].
+ *                       n_cols must be 2^s and n_rows <= 2^s (missing rows are zero: pad_rows,
+ *                       src/sparse_matrix.rs:104-108); else ZIP_ERR_SHAPE, where the reference panics
+ *                       or returns LengthsNotEqual (src/ccs/utils.rs:52-59).
+ *   zip_ccs_set_z       z = x || 1 || w (Statement_Z::get_z_vector), z_len <= 2^s, zero-extended
+ *                       (prover.rs:230-232): builds z_ccs in F_q (:236) and the t tables M_k z
+ *                       (calculate_Mz_mles, src/zinc/utils.rs:121-135)
+ *   zip_ccs_eq_table    build_eq_x_r(r) (src/sumcheck/utils.rs:102-177), r = s Montgomery elements on
+ *                       the HOST; slot 0 is for eq(beta) (prepare_lin_sumcheck_polynomial,
+ *                       zinc/utils.rs:72), slot 1 for eq(r_x)
+ *   zip_ccs_second_table  what sumcheck_2 needs (prover.rs:261-296): eq(r_x) into slot 1, the table
+ *                       sum_k gamma^k * compute_eval_table_sparse(M_k, eq(r_x)) (src/sparse_matrix.rs:165-182),
+ *                       and V_s[k] = (M_k z)(r_x) (calculate_V_s, prover.rs:330-347) to v_s_out (HOST, t elements)
+ *   zip_ccs_table       device pointer of a table of 2^s elements, valid until the next call that
+ *                       rebuilds it or zip_ccs_free; index = matrix for ZIP_CCS_MZ, slot for ZIP_CCS_EQ
+ *   zip_ccs_download    the same table copied to the HOST (tests) */
+typedef struct zip_ccs zip_ccs;
+typedef struct {
+    uint32_t n_rows, n_cols;
+    const uint32_t *row_ptr, *col_idx;
+    const int64_t *values;
+} zip_sparse_matrix;
+typedef enum { ZIP_CCS_Z_FIELD = 0, ZIP_CCS_MZ = 1, ZIP_CCS_EQ = 2, ZIP_CCS_SECOND = 3 } zip_ccs_table_kind;
+int32_t zip_ccs_create(int32_t device, const zip_sparse_matrix *matrices, uint32_t t, uint32_t s, const zip_field *field,
+                       zip_ccs **out);
+void zip_ccs_free(zip_ccs *c);
+const char *zip_ccs_last_error(const zip_ccs *c);
+int32_t zip_ccs_set_z(zip_ccs *c, const int64_t *z, size_t z_len, zip_mem_kind kind);
+int32_t zip_ccs_eq_table(zip_ccs *c, const uint64_t *r, uint32_t slot);
+int32_t zip_ccs_second_table(zip_ccs *c, const uint64_t *r_x, const uint64_t *gamma, uint64_t *v_s_out);
+int32_t zip_ccs_table(zip_ccs *c, zip_ccs_table_kind which, uint32_t index, const uint64_t **table_dev);
+int32_t zip_ccs_download(zip_ccs *c, zip_ccs_table_kind which, uint32_t index, uint64_t *out);
+
 /* Diagnostic: FieldMap for Int<4> (src/conversion.rs:86-100) of n arbitrary 256-bit values, as the
  * verifier applies it to column entries.  values: HOST n*4 limbs; out: HOST n*limbs Montgomery limbs. */
 int32_t zip_field_map_int256(zip_ctx *ctx, const uint64_t *values, uint32_t n, const zip_field *field, uint64_t *out);

@@ -1,0 +1,172 @@
+"""ZincProver on the device (BASELINE configs[4]): the field loops of SpartanProver::prove (zip_ccs_*), the two
+sumchecks (zip_sumcheck_*) and the Zip PCS step, driven by the host mirror with the transcript on the host, against
+the oracle's restatement of src/zinc/prover.rs and checked by the oracle's restatement of src/zinc/verifier.rs.
+Restates src/zinc/tests.rs."""
+import numpy as np
+import pytest
+
+import _ccs
+import _oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+Q192 = 312829638388039969874974628075306023441          # zinc/tests.rs:28
+Q256 = 115792089237316195423570985008687907853269984665640564039457584007913129639747  # spartan_benches.rs:152 (top bit set)
+QSTARK = 3618502788666131213697322783095070105623107215331596699973092056135872020481  # spartan_benches.rs:161
+Q128 = 57316695564490278656402085503
+FIELDS = [(Q192, 3), (Q256, 4), (QSTARK, 4), (Q128, 2)]
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from zinc_amd import cabi, pcs
+
+    if cabi.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu tests must run on the MI355X box")
+    return cabi, pcs
+
+
+def _instances():
+    return [("dummy2", _ccs.dummy_ccs_from_len(2)), ("dummy8", _ccs.dummy_ccs_from_len(8)),
+            ("dummy1k", _ccs.dummy_ccs_from_len(1 << 10, seed=77)), ("vitalik", _ccs.vitalik_ccs(3))]
+
+
+@pytest.mark.parametrize("q,fl", FIELDS)
+@pytest.mark.parametrize("name,inst", _instances())
+def test_ccs_tables_equal_the_oracle(mods, q, fl, name, inst):
+    """z_ccs in F_q, M_k z, eq(beta), eq(r_x), the second sumcheck's table and V_s, one by one."""
+    cabi, _ = mods
+    f = orc.make_field(q, fl)
+    o = orc.Ccs(inst)
+    d = cabi.Ccs(inst.matrices, inst.s, cabi.make_field(q, fl))
+    d.set_z(inst.z)
+    zf = d.download(cabi.CCS_Z_FIELD)
+    for i in range(inst.m):
+        want = orc.field_from_i64(f, int(inst.z[i])) if i < len(inst.z) else 0
+        assert orc.limbs_to_int(zf[i]) == want, i
+    mz_o = o.mz(f)
+    for k in range(inst.t):
+        assert np.array_equal(d.download(cabi.CCS_MZ, k), mz_o[k]), k
+    rng = np.random.default_rng(inst.s)
+    r = orc.field_elems([orc.field_from_i64(f, int(v)) for v in rng.integers(-2**62, 2**62, size=inst.s)], fl)
+    gamma = orc.field_elems([orc.field_from_i64(f, 0x1234567890ABCDEF)], fl)[0]
+    eq_o = orc.build_eq_x_r(f, r)
+    d.eq_table(r, 0)
+    assert np.array_equal(d.download(cabi.CCS_EQ, 0), eq_o)
+    vs = d.second_table(r, gamma)
+    assert np.array_equal(d.download(cabi.CCS_EQ, 1), eq_o)
+    assert np.array_equal(d.download(cabi.CCS_SECOND), o.second_table(f, eq_o, gamma))
+    for k in range(inst.t):  # V_s[k] = <Mz_k, eq(r_x)>
+        acc = 0
+        for i in range(inst.m):
+            acc = orc.field_add(f, acc, orc.field_mul(f, orc.limbs_to_int(mz_o[k, i]), orc.limbs_to_int(eq_o[i])))
+        assert orc.limbs_to_int(vs[k]) == acc
+    d.free()
+
+
+def test_ccs_shape_errors(mods):
+    cabi, _ = mods
+    inst = _ccs.dummy_ccs_from_len(8)
+    field = cabi.make_field(Q192, 3)
+    with pytest.raises(cabi.ZipError):  # n_cols != 2^s: LengthsNotEqual in mat_vec_mul
+        cabi.Ccs(inst.matrices, 2, field)
+    d = cabi.Ccs(inst.matrices, 3, field)
+    with pytest.raises(cabi.ZipError):
+        d.set_z(np.zeros(9, dtype=np.int64))
+    with pytest.raises(cabi.ZipError):  # nothing built yet
+        d.table(cabi.CCS_SECOND)
+    d.free()
+
+
+def _device_spartan(pcs, inst, q, fl, label=b"", with_pcs=False):
+    field = pcs.FieldConfig(q, fl)
+    t = pcs.KeccakTranscript()
+    if label:
+        t.absorb(label)
+    prover = pcs.ZincProver()
+    x, w = inst.z[:1], inst.z[2:]  # z = (x, 1, w), pub_io_len = 1
+    fn = prover.prove if with_pcs else prover.spartan_prove
+    return fn(inst.matrices, inst.s, inst.d, inst.S, inst.c, x, w, t, field), t
+
+
+@pytest.mark.parametrize("q,fl", FIELDS)
+@pytest.mark.parametrize("name,inst", _instances() + [("dummy8k", _ccs.dummy_ccs_from_len(1 << 13, seed=5))])
+def test_spartan_prove_equals_the_oracle(mods, q, fl, name, inst):
+    """SpartanProver::prove: every round message of both sumchecks, V_s and r_y; the verifier accepts."""
+    _, pcs = mods
+    f = orc.make_field(q, fl)
+    o = orc.Ccs(inst)
+    want = o.spartan_prove(f, orc.new_transcript())
+    got, _ = _device_spartan(pcs, inst, q, fl)
+    for key in ("msgs1", "msgs2", "V_s", "r_y"):
+        assert np.array_equal(got[key], want[key]), key
+    rc, pts = o.spartan_verify(f, got, orc.new_transcript())
+    assert rc == 0 and np.array_equal(pts["r_y"], got["r_y"])
+
+
+def test_dummy_spartan_prover_and_verifier_reference_size(mods):
+    """zinc/tests.rs:22-57 and :110-157: n = 2^13, the 192-bit prime, prove then verify."""
+    _, pcs = mods
+    inst = _ccs.dummy_ccs_from_len(1 << 13)
+    got, _ = _device_spartan(pcs, inst, Q192, 3)
+    rc, _ = orc.Ccs(inst).spartan_verify(orc.make_field(Q192, 3), got, orc.new_transcript())
+    assert rc == 0
+
+
+def test_spartan_verifier_and_failing_verifier(mods):
+    """zinc/tests.rs:59-108 and :159-209 (x^3 + x + 5 = y at x = 3; then w_ccs[3] = 0)."""
+    _, pcs = mods
+    f = orc.make_field(Q192, 3)
+    good = _ccs.vitalik_ccs(3)
+    got, _ = _device_spartan(pcs, good, Q192, 3)
+    assert orc.Ccs(good).spartan_verify(f, got, orc.new_transcript())[0] == 0
+    bad = _ccs.vitalik_ccs(3, break_witness=True)
+    got, _ = _device_spartan(pcs, bad, Q192, 3)  # the prover still succeeds (tests.rs:184-193)
+    assert np.array_equal(got["msgs1"], orc.Ccs(bad).spartan_prove(f, orc.new_transcript())["msgs1"])
+    assert orc.Ccs(bad).spartan_verify(f, got, orc.new_transcript())[0] == orc.ORC_ERR_PROOF
+
+
+@pytest.mark.parametrize("q,fl,log_n", [(Q192, 3, 4), (QSTARK, 4, 10), (Q256, 4, 8), (Q192, 3, 13)])
+def test_zinc_prove_end_to_end(mods, q, fl, log_n):
+    """Prover::prove (prover.rs:50-88): the Spartan proof, then RaaCode::new from the same transcript, commit, the
+    evaluation v and the PCS proof -- all equal to the oracle's; the oracle's ZincVerifier steps
+    (SpartanVerifier::verify, MultilinearZip::verify, the final equation of verify_pcs_proof) accept."""
+    _, pcs = mods
+    inst = _ccs.dummy_ccs_from_len(1 << log_n, seed=log_n)
+    f = orc.make_field(q, fl)
+    o = orc.Ccs(inst)
+    # oracle prover
+    ko = orc.new_transcript()
+    orc.absorb(ko, b"zinc")
+    want = o.spartan_prove(f, ko)
+    s1 = orc.lib().orc_tr_get_u64(orc.C.byref(ko))
+    s2 = orc.lib().orc_tr_get_u64(orc.C.byref(ko))
+    z = orc.Zip(log_n, seeds=(s1, s2))
+    rows, layers, roots_o = z.commit(inst.z)
+    proof_o, _, _ = z.open(f, inst.z, rows, layers, want["r_y"], orc.new_transcript())
+    v_o = z.mle_eval(f, inst.z, want["r_y"])
+    # device prover
+    got, _ = _device_spartan(pcs, inst, q, fl, label=b"zinc", with_pcs=True)
+    for key in ("msgs1", "msgs2", "V_s", "r_y"):
+        assert np.array_equal(got[key], want[key]), key
+    zp = got["zip_proof"]
+    assert np.array_equal(zp["z_comm"], roots_o)
+    assert orc.limbs_to_int(zp["v"]) == v_o
+    assert np.array_equal(zp["pcs_proof"], proof_o)
+    # oracle verifier over the device's proof
+    kv = orc.new_transcript()
+    orc.absorb(kv, b"zinc")
+    rc, pts = o.spartan_verify(f, got, kv)
+    assert rc == 0
+    t1 = orc.lib().orc_tr_get_u64(orc.C.byref(kv))
+    t2 = orc.lib().orc_tr_get_u64(orc.C.byref(kv))
+    assert (t1, t2) == (s1, s2)
+    pcs_rc = z.verify(f, zp["z_comm"], pts["r_y"], orc.limbs_to_int(zp["v"]), zp["pcs_proof"])
+    if q == Q256:  # the reference rejects its own PCS proofs for a modulus with the top bit set
+        assert pcs_rc != 0
+    else:
+        assert pcs_rc == 0
+    assert o.final_check(f, pts, zp["v"]) == 0
+    wrong = zp["v"].copy()
+    wrong[0] ^= np.uint64(1)
+    assert o.final_check(f, pts, wrong) == orc.ORC_ERR_PROOF

@@ -30,6 +30,8 @@ EXPORTED_SYMBOLS = (
     "zip_open_columns", "zip_open_eval", "zip_proof_len", "zip_open", "zip_sum_partials", "zip_merkle_trees",
     "zip_ctx_set_profiling", "zip_ctx_profile_read", "zip_verify", "zip_mle_eval", "zip_field_map_int256",
     "zip_open_stream", "zip_sumcheck_init", "zip_sumcheck_round", "zip_sumcheck_last_error", "zip_sumcheck_free",
+    "zip_ccs_create", "zip_ccs_free", "zip_ccs_last_error", "zip_ccs_set_z", "zip_ccs_eq_table",
+    "zip_ccs_second_table", "zip_ccs_table", "zip_ccs_download",
 )
 
 
@@ -78,6 +80,14 @@ def make_comb(term_masks, coeffs_limbs):
             c.coeff[t][i] = int(cl[t, i])
     return c
 
+
+class SparseMatrix(C.Structure):
+    """zip_sparse_matrix: SparseMatrix<Int<1>> as CSR"""
+    _fields_ = [("n_rows", C.c_uint32), ("n_cols", C.c_uint32), ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p),
+                ("values", C.c_void_p)]
+
+
+CCS_Z_FIELD, CCS_MZ, CCS_EQ, CCS_SECOND = 0, 1, 2, 3
 
 PROOF_SINK = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -133,6 +143,17 @@ def lib():
     L.zip_sumcheck_last_error.restype = C.c_char_p
     L.zip_sumcheck_free.argtypes = [vp]
     L.zip_sumcheck_free.restype = None
+    L.zip_ccs_create.argtypes = [C.c_int32, C.POINTER(SparseMatrix), C.c_uint32, C.c_uint32, C.POINTER(ZipField),
+                                 C.POINTER(vp)]
+    L.zip_ccs_free.argtypes = [vp]
+    L.zip_ccs_free.restype = None
+    L.zip_ccs_last_error.argtypes = [vp]
+    L.zip_ccs_last_error.restype = C.c_char_p
+    L.zip_ccs_set_z.argtypes = [vp, i64p, C.c_size_t, C.c_int]
+    L.zip_ccs_eq_table.argtypes = [vp, u64p, C.c_uint32]
+    L.zip_ccs_second_table.argtypes = [vp, u64p, u64p, u64p]
+    L.zip_ccs_table.argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(vp)]
+    L.zip_ccs_download.argtypes = [vp, C.c_int, C.c_uint32, u64p]
     L.zip_commitment_free.argtypes = [vp]
     L.zip_commitment_free.restype = None
     L.zip_commitment_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
@@ -457,9 +478,9 @@ class Sumcheck:
             self._keep = np.ascontiguousarray(mles, dtype=np.uint64)
             ptrs = [self._keep[k].ctypes.data for k in range(self._keep.shape[0])]
             kind = MEM_HOST
-        else:
+        else:  # CUDA tensors, or raw device addresses (zip_ccs tables)
             self._keep = list(mles)
-            ptrs = [t.data_ptr() for t in self._keep]
+            ptrs = [t if isinstance(t, int) else t.data_ptr() for t in self._keep]
             kind = MEM_DEVICE
         arr = (C.c_void_p * len(ptrs))(*ptrs)
         h = C.c_void_p()
@@ -480,6 +501,73 @@ class Sumcheck:
     def free(self):
         if getattr(self, "_h", None):
             lib().zip_sumcheck_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Ccs:
+    """zip_ccs: the CCS matrices and the tables of SpartanProver::prove in HBM.
+    matrices: objects with n_rows, n_cols, row_ptr (uint32), col_idx (uint32), values (int64) numpy arrays."""
+
+    def __init__(self, matrices, s, field: ZipField, device=0):
+        self.field, self.s, self.t, self.m = field, s, len(matrices), 1 << s
+        self._keep = [(np.ascontiguousarray(M.row_ptr, dtype=np.uint32), np.ascontiguousarray(M.col_idx, dtype=np.uint32),
+                       np.ascontiguousarray(M.values, dtype=np.int64)) for M in matrices]
+        arr = (SparseMatrix * self.t)()
+        for k, (M, (rp, ci, va)) in enumerate(zip(matrices, self._keep)):
+            arr[k] = SparseMatrix(M.n_rows, M.n_cols, rp.ctypes.data, ci.ctypes.data, va.ctypes.data)
+        h = C.c_void_p()
+        rc = lib().zip_ccs_create(device, arr, self.t, s, C.byref(field), C.byref(h))
+        if rc != ZIP_OK:
+            raise ZipError(rc, "zip_ccs_create", strerror(rc))
+        self._h = h
+
+    def _check(self, rc, what):
+        if rc != ZIP_OK:
+            raise ZipError(rc, what, lib().zip_ccs_last_error(self._h).decode())
+
+    def set_z(self, z):
+        """z: numpy int64 (host) or a CUDA int64 tensor"""
+        if isinstance(z, np.ndarray):
+            z = np.ascontiguousarray(z, dtype=np.int64)
+            self._check(lib().zip_ccs_set_z(self._h, z.ctypes.data, z.size, MEM_HOST), "zip_ccs_set_z")
+        else:
+            self._check(lib().zip_ccs_set_z(self._h, z.data_ptr(), z.numel(), MEM_DEVICE), "zip_ccs_set_z")
+
+    def eq_table(self, r, slot):
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        assert r.shape == (self.s, self.field.limbs)
+        self._check(lib().zip_ccs_eq_table(self._h, r.ctypes.data, slot), "zip_ccs_eq_table")
+
+    def second_table(self, r_x, gamma):
+        """Returns V_s [t, limbs]."""
+        r_x = np.ascontiguousarray(r_x, dtype=np.uint64)
+        gamma = np.ascontiguousarray(gamma, dtype=np.uint64)
+        assert r_x.shape == (self.s, self.field.limbs) and gamma.shape == (self.field.limbs,)
+        vs = np.zeros((self.t, self.field.limbs), dtype=np.uint64)
+        self._check(lib().zip_ccs_second_table(self._h, r_x.ctypes.data, gamma.ctypes.data, vs.ctypes.data),
+                    "zip_ccs_second_table")
+        return vs
+
+    def table(self, which, index=0) -> int:
+        """Device address of a table of 2^s field elements."""
+        p = C.c_void_p()
+        self._check(lib().zip_ccs_table(self._h, which, index, C.byref(p)), "zip_ccs_table")
+        return int(p.value)
+
+    def download(self, which, index=0):
+        out = np.zeros((self.m, self.field.limbs), dtype=np.uint64)
+        self._check(lib().zip_ccs_download(self._h, which, index, out.ctypes.data), "zip_ccs_download")
+        return out
+
+    def free(self):
+        if getattr(self, "_h", None):
+            lib().zip_ccs_free(self._h)
         self._h = None
 
     def __del__(self):

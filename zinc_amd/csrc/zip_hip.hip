@@ -22,6 +22,7 @@
 #include "kernels_open.cuh"
 #include "kernels_verify.cuh"
 #include "kernels_sumcheck.cuh"
+#include "kernels_spartan.cuh"
 
 using namespace zipk;
 
@@ -111,6 +112,22 @@ struct zip_sumcheck {
     uint64_t modulus[8] = {};
     uint32_t n_terms = 0, term_mask[8] = {};  // zip_sumcheck_comb, or n_terms == 0 for the plain product
     uint64_t coeff[8][8] = {};
+};
+
+// CCS matrices and the per-proof tables of SpartanProver::prove (src/zinc/prover.rs:130-161) in HBM.
+struct zip_ccs {
+    zip_ctx *ctx = nullptr;  // private plumbing context (stream, pool, error text)
+    uint32_t t = 0, s = 0, m = 0, fl = 0;
+    uint64_t modulus[8] = {};
+    struct Mat {
+        uint32_t n_rows = 0, nnz = 0;
+        uint32_t *row_ptr = nullptr, *col_idx = nullptr, *col_ptr = nullptr, *row_idx = nullptr;
+        uint64_t *vals = nullptr, *vals_t = nullptr;  // Montgomery: CSR order / CSC order
+    } mat[kCcsMaxMatrices];
+    uint64_t *z_f = nullptr, *mz[kCcsMaxMatrices] = {}, *eq[2] = {}, *second = nullptr;
+    uint64_t *small_d = nullptr, *partials = nullptr;  // challenges in; dot-product partials
+    uint32_t dot_blocks = 0;
+    bool have_z = false, have_eq[2] = {false, false}, have_second = false;
 };
 
 namespace {
@@ -982,6 +999,87 @@ int32_t sumcheck_round_fl(zip_sumcheck *s, const uint64_t *r_prev, const HostFie
         case 3: return sumcheck_round_k<FL, 3>(s, a, blocks, fd);
         default: return sumcheck_round_k<FL, 4>(s, a, blocks, fd);
     }
+}
+
+// ------------------------------------------------------------------ Spartan pieces
+template <int FL>
+int32_t ccs_map_i64(zip_ctx *ctx, const int64_t *in_d, uint64_t n_in, uint64_t n_out, uint64_t *out_d, const HostField &hf) {
+    if (!n_out) return ZIP_OK;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_out + 255) / 256, 65535);
+    LaunchTimer t(ctx, "field_map_i64_kernel");
+    hipLaunchKernelGGL(field_map_i64_kernel<FL>, dim3(blocks), dim3(256), 0, ctx->stream, in_d, n_in, n_out, out_d,
+                       to_dev<FL>(hf), hf.quirk_mod);
+    HIP_TRY(ctx, hipGetLastError());
+    return ZIP_OK;
+}
+
+template <int FL>
+int32_t ccs_set_z_fl(zip_ccs *c, const int64_t *z_d, size_t z_len, const HostField &hf) {
+    zip_ctx *ctx = c->ctx;
+    int32_t rc;
+    if ((rc = ccs_map_i64<FL>(ctx, z_d, z_len, c->m, c->z_f, hf))) return rc;
+    const FieldDev<FL> fd = to_dev<FL>(hf);
+    for (uint32_t k = 0; k < c->t; k++) {
+        LaunchTimer t(ctx, "spmv_rows_kernel");
+        hipLaunchKernelGGL(spmv_rows_kernel<FL>, dim3((c->m + 255) / 256), dim3(256), 0, ctx->stream, c->mat[k].row_ptr,
+                           c->mat[k].col_idx, c->mat[k].vals, c->z_f, c->mat[k].n_rows, c->m, c->mz[k], fd);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return ZIP_OK;
+}
+
+template <int FL>
+int32_t ccs_eq_table_fl(zip_ccs *c, const uint64_t *r_d, uint32_t slot, const HostField &hf) {
+    zip_ctx *ctx = c->ctx;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)c->m + 255) / 256, 65535);
+    LaunchTimer t(ctx, "eq_table_kernel");
+    hipLaunchKernelGGL(eq_table_kernel<FL>, dim3(blocks), dim3(256), 0, ctx->stream, r_d, c->s, c->eq[slot], to_dev<FL>(hf));
+    HIP_TRY(ctx, hipGetLastError());
+    return ZIP_OK;
+}
+
+template <int FL>
+int32_t ccs_second_fl(zip_ccs *c, const uint64_t *gamma_d, uint64_t *vs_d, const HostField &hf) {
+    zip_ctx *ctx = c->ctx;
+    const FieldDev<FL> fd = to_dev<FL>(hf);
+    SecondTableArgs a{};
+    for (uint32_t k = 0; k < c->t; k++) {
+        a.col_ptr[k] = c->mat[k].col_ptr;
+        a.row_idx[k] = c->mat[k].row_idx;
+        a.vals[k] = c->mat[k].vals_t;
+    }
+    a.t = c->t;
+    a.m = c->m;
+    a.eq = c->eq[1];
+    a.out = c->second;
+    {
+        LaunchTimer t(ctx, "second_table_kernel");
+        hipLaunchKernelGGL(second_table_kernel<FL>, dim3((c->m + 255) / 256), dim3(256), 0, ctx->stream, a, gamma_d, fd);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    for (uint32_t k = 0; k < c->t; k++) {  // calculate_V_s
+        LaunchTimer t(ctx, "field_dot_partials_kernel");
+        hipLaunchKernelGGL(field_dot_partials_kernel<FL>, dim3(c->dot_blocks), dim3(256), 0, ctx->stream, c->mz[k], c->eq[1],
+                           (uint64_t)c->m, c->partials, fd);
+        hipLaunchKernelGGL(sumcheck_reduce_kernel<FL>, dim3(1), dim3(256), 0, ctx->stream, c->partials, c->dot_blocks, 1u,
+                           vs_d + (size_t)k * FL, fd);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return ZIP_OK;
+}
+
+#define CCS_DISPATCH_FL(fl, fn, ...)                  \
+    switch (fl) {                                     \
+        case 2: rc = fn<2>(__VA_ARGS__); break;       \
+        case 3: rc = fn<3>(__VA_ARGS__); break;       \
+        default: rc = fn<4>(__VA_ARGS__); break;      \
+    }
+
+int32_t ccs_field(zip_ccs *c, HostField *hf) {
+    zip_field zf{};
+    zf.limbs = c->fl;
+    memcpy(zf.modulus, c->modulus, sizeof zf.modulus);
+    return make_field(c->ctx, &zf, hf);
 }
 }  // namespace
 
@@ -1899,6 +1997,213 @@ void zip_sumcheck_free(zip_sumcheck *s) {
         zip_ctx_destroy(s->ctx);  // frees every pool block, the stream, the events
     }
     delete s;
+}
+
+// ---------------------------------------------------------------------------- zip_ccs
+int32_t zip_ccs_create(int32_t device, const zip_sparse_matrix *mats, uint32_t t, uint32_t s, const zip_field *field,
+                       zip_ccs **out) {
+    if (!mats || !out || !field) return ZIP_ERR_NULL;
+    *out = nullptr;
+    if (t < 1 || t > (uint32_t)kCcsMaxMatrices || s < 1 || s > 28) return ZIP_ERR_INVALID_PARAM;
+    const uint32_t m = 1u << s;
+    for (uint32_t k = 0; k < t; k++) {
+        const zip_sparse_matrix &M = mats[k];
+        if (!M.row_ptr || (M.row_ptr[M.n_rows] && (!M.col_idx || !M.values))) return ZIP_ERR_NULL;
+        // mat_vec_mul: "M.n_cols != z.len()" (ccs/utils.rs:52-59); more rows than 2^s: to_mles_err (zinc/utils.rs:150)
+        if (M.n_cols != m || M.n_rows > m) return ZIP_ERR_SHAPE;
+        if (M.row_ptr[0] != 0) return ZIP_ERR_INVALID_PARAM;
+        for (uint32_t r = 0; r < M.n_rows; r++)
+            if (M.row_ptr[r + 1] < M.row_ptr[r]) return ZIP_ERR_INVALID_PARAM;
+        for (uint32_t e = 0; e < M.row_ptr[M.n_rows]; e++)
+            if (M.col_idx[e] >= m) return ZIP_ERR_SHAPE;  // the reference indexes out of bounds (panic)
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return ZIP_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return ZIP_ERR_NO_DEVICE;
+    zip_ctx *ctx = new (std::nothrow) zip_ctx();
+    zip_ccs *c = new (std::nothrow) zip_ccs();
+    if (!ctx || !c) { delete ctx; delete c; return ZIP_ERR_ALLOC; }
+    ctx->device = device;
+    c->ctx = ctx;
+    int32_t rc = ZIP_OK;
+    do {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
+        HostField hf;
+        if ((rc = make_field(ctx, field, &hf))) break;
+        c->t = t;
+        c->s = s;
+        c->m = m;
+        c->fl = hf.fl;
+        memcpy(c->modulus, hf.modulus, sizeof c->modulus);
+        const size_t elem = (size_t)hf.fl * 8, tab = (size_t)m * elem;
+        for (uint32_t k = 0; k < t && rc == ZIP_OK; k++) {
+            const zip_sparse_matrix &M = mats[k];
+            zip_ccs::Mat &D = c->mat[k];
+            const uint32_t nnz = M.row_ptr[M.n_rows];
+            D.n_rows = M.n_rows;
+            D.nnz = nnz;
+            // the transposed form: a counting sort by column (rows stay ascending inside a column)
+            std::vector<uint32_t> col_ptr((size_t)m + 1, 0), row_idx(nnz);
+            std::vector<int64_t> vals_t(nnz);
+            for (uint32_t e = 0; e < nnz; e++) col_ptr[M.col_idx[e] + 1]++;
+            for (uint32_t col = 0; col < m; col++) col_ptr[col + 1] += col_ptr[col];
+            {
+                std::vector<uint32_t> next(col_ptr.begin(), col_ptr.end() - 1);
+                for (uint32_t r = 0; r < M.n_rows; r++)
+                    for (uint32_t e = M.row_ptr[r]; e < M.row_ptr[r + 1]; e++) {
+                        const uint32_t dst = next[M.col_idx[e]]++;
+                        row_idx[dst] = r;
+                        vals_t[dst] = M.values[e];
+                    }
+            }
+            void *tmp = nullptr;  // i64 values before the field map
+            if ((rc = pool_alloc(ctx, (size_t)(M.n_rows + 1) * 4, (void **)&D.row_ptr))) break;
+            if ((rc = pool_alloc(ctx, (size_t)nnz * 4, (void **)&D.col_idx))) break;
+            if ((rc = pool_alloc(ctx, ((size_t)m + 1) * 4, (void **)&D.col_ptr))) break;
+            if ((rc = pool_alloc(ctx, (size_t)nnz * 4, (void **)&D.row_idx))) break;
+            if ((rc = pool_alloc(ctx, (size_t)nnz * elem, (void **)&D.vals))) break;
+            if ((rc = pool_alloc(ctx, (size_t)nnz * elem, (void **)&D.vals_t))) break;
+            if ((rc = pool_alloc(ctx, (size_t)nnz * 8, &tmp))) break;
+            if ((rc = copy_h2d_bounced(ctx, D.row_ptr, M.row_ptr, (size_t)(M.n_rows + 1) * 4, ctx->stream))) break;
+            if ((rc = copy_h2d_bounced(ctx, D.col_ptr, col_ptr.data(), ((size_t)m + 1) * 4, ctx->stream))) break;
+            if (nnz) {
+                if ((rc = copy_h2d_bounced(ctx, D.col_idx, M.col_idx, (size_t)nnz * 4, ctx->stream))) break;
+                if ((rc = copy_h2d_bounced(ctx, D.row_idx, row_idx.data(), (size_t)nnz * 4, ctx->stream))) break;
+                // SparseMatrix::map_to_field (sparse_matrix.rs:38-58), once per order
+                if ((rc = copy_h2d_bounced(ctx, tmp, M.values, (size_t)nnz * 8, ctx->stream))) break;
+                CCS_DISPATCH_FL(hf.fl, ccs_map_i64, ctx, static_cast<const int64_t *>(tmp), nnz, nnz, D.vals, hf);
+                if (rc) break;
+                if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }  // tmp is reused
+                if ((rc = copy_h2d_bounced(ctx, tmp, vals_t.data(), (size_t)nnz * 8, ctx->stream))) break;
+                CCS_DISPATCH_FL(hf.fl, ccs_map_i64, ctx, static_cast<const int64_t *>(tmp), nnz, nnz, D.vals_t, hf);
+                if (rc) break;
+            }
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
+            pool_release(ctx, tmp);
+            if ((rc = pool_alloc(ctx, tab, (void **)&c->mz[k]))) break;
+        }
+        if (rc) break;
+        if ((rc = pool_alloc(ctx, tab, (void **)&c->z_f))) break;
+        if ((rc = pool_alloc(ctx, tab, (void **)&c->eq[0]))) break;
+        if ((rc = pool_alloc(ctx, tab, (void **)&c->eq[1]))) break;
+        if ((rc = pool_alloc(ctx, tab, (void **)&c->second))) break;
+        if ((rc = pool_alloc(ctx, (size_t)(40 + kCcsMaxMatrices) * 64, (void **)&c->small_d))) break;
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        c->dot_blocks = (uint32_t)std::min<uint64_t>(((uint64_t)m + 255) / 256, (uint64_t)cus * 4);
+        if ((rc = pool_alloc(ctx, (size_t)c->dot_blocks * elem, (void **)&c->partials))) break;
+    } while (0);
+    if (rc) {
+        zip_ccs_free(c);
+        return rc;
+    }
+    *out = c;
+    return ZIP_OK;
+}
+
+void zip_ccs_free(zip_ccs *c) {
+    if (!c) return;
+    if (c->ctx) zip_ctx_destroy(c->ctx);  // frees every pool block and the stream
+    delete c;
+}
+
+const char *zip_ccs_last_error(const zip_ccs *c) { return c && c->ctx ? c->ctx->last_error.c_str() : ""; }
+
+int32_t zip_ccs_set_z(zip_ccs *c, const int64_t *z, size_t z_len, zip_mem_kind kind) {
+    if (!c || (!z && z_len)) return ZIP_ERR_NULL;
+    zip_ctx *ctx = c->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
+    if (z_len > c->m) return fail(ctx, ZIP_ERR_SHAPE, "z has %zu entries, the matrices %u columns", z_len, c->m);
+    HostField hf;
+    int32_t rc;
+    if ((rc = ccs_field(c, &hf))) return rc;
+    Scratch in(ctx);
+    const int64_t *z_d = z;
+    if (kind == ZIP_MEM_HOST && z_len) {
+        if ((rc = in.get(z_len * 8))) return rc;
+        if ((rc = copy_h2d_bounced(ctx, in.ptr, z, z_len * 8, ctx->stream))) return rc;
+        z_d = in.as<int64_t>();
+    }
+    CCS_DISPATCH_FL(c->fl, ccs_set_z_fl, c, z_d, z_len, hf);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    c->have_z = true;
+    c->have_second = false;
+    return ZIP_OK;
+}
+
+int32_t zip_ccs_eq_table(zip_ccs *c, const uint64_t *r, uint32_t slot) {
+    if (!c || !r) return ZIP_ERR_NULL;
+    zip_ctx *ctx = c->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
+    if (slot > 1) return fail(ctx, ZIP_ERR_INVALID_PARAM, "slot %u: 0 = eq(beta), 1 = eq(r_x)", slot);
+    HostField hf;
+    int32_t rc;
+    if ((rc = ccs_field(c, &hf))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(c->small_d, r, (size_t)c->s * c->fl * 8, hipMemcpyHostToDevice, ctx->stream));
+    CCS_DISPATCH_FL(c->fl, ccs_eq_table_fl, c, c->small_d, slot, hf);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    c->have_eq[slot] = true;
+    return ZIP_OK;
+}
+
+int32_t zip_ccs_second_table(zip_ccs *c, const uint64_t *r_x, const uint64_t *gamma, uint64_t *v_s_out) {
+    if (!c || !r_x || !gamma || !v_s_out) return ZIP_ERR_NULL;
+    zip_ctx *ctx = c->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
+    if (!c->have_z) return fail(ctx, ZIP_ERR_INVALID_PARAM, "zip_ccs_set_z has not run");
+    int32_t rc;
+    if ((rc = zip_ccs_eq_table(c, r_x, 1))) return rc;
+    HostField hf;
+    if ((rc = ccs_field(c, &hf))) return rc;
+    uint64_t *gamma_d = c->small_d + (size_t)32 * 8, *vs_d = c->small_d + (size_t)33 * 8;
+    HIP_TRY(ctx, hipMemcpyAsync(gamma_d, gamma, (size_t)c->fl * 8, hipMemcpyHostToDevice, ctx->stream));
+    CCS_DISPATCH_FL(c->fl, ccs_second_fl, c, gamma_d, vs_d, hf);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(v_s_out, vs_d, (size_t)c->t * c->fl * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    c->have_second = true;
+    return ZIP_OK;
+}
+
+int32_t zip_ccs_table(zip_ccs *c, zip_ccs_table_kind which, uint32_t index, const uint64_t **table_dev) {
+    if (!c || !table_dev) return ZIP_ERR_NULL;
+    zip_ctx *ctx = c->ctx;
+    *table_dev = nullptr;
+    switch (which) {
+        case ZIP_CCS_Z_FIELD:
+            if (!c->have_z) return fail(ctx, ZIP_ERR_INVALID_PARAM, "zip_ccs_set_z has not run");
+            *table_dev = c->z_f;
+            return ZIP_OK;
+        case ZIP_CCS_MZ:
+            if (!c->have_z) return fail(ctx, ZIP_ERR_INVALID_PARAM, "zip_ccs_set_z has not run");
+            if (index >= c->t) return fail(ctx, ZIP_ERR_INVALID_PARAM, "matrix %u of %u", index, c->t);
+            *table_dev = c->mz[index];
+            return ZIP_OK;
+        case ZIP_CCS_EQ:
+            if (index > 1 || !c->have_eq[index]) return fail(ctx, ZIP_ERR_INVALID_PARAM, "eq table %u has not been built", index);
+            *table_dev = c->eq[index];
+            return ZIP_OK;
+        case ZIP_CCS_SECOND:
+            if (!c->have_second) return fail(ctx, ZIP_ERR_INVALID_PARAM, "zip_ccs_second_table has not run");
+            *table_dev = c->second;
+            return ZIP_OK;
+    }
+    return fail(ctx, ZIP_ERR_INVALID_PARAM, "unknown table kind %d", (int)which);
+}
+
+int32_t zip_ccs_download(zip_ccs *c, zip_ccs_table_kind which, uint32_t index, uint64_t *out) {
+    if (!c || !out) return ZIP_ERR_NULL;
+    const uint64_t *d = nullptr;
+    int32_t rc = zip_ccs_table(c, which, index, &d);
+    if (rc) return rc;
+    zip_ctx *ctx = c->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return copy_d2h_bounced(ctx, out, d, (size_t)c->m * c->fl * 8, ctx->stream);
 }
 
 int32_t zip_sum_partials(zip_ctx *ctx, const uint64_t *uparts, const uint64_t *fparts, uint32_t n_parts,

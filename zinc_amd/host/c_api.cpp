@@ -320,4 +320,69 @@ int32_t zinc_sumcheck_prove_ccs(zinc_transcript *transcript, const uint64_t *con
     });
 }
 
+int32_t zinc_prover_prove(const zip_sparse_matrix *constraints, uint32_t t, uint32_t s, uint32_t d, uint32_t q,
+                          const uint32_t *s_masks, const int64_t *c, const int64_t *public_input, size_t l,
+                          const int64_t *w_ccs, size_t w_len, zinc_transcript *transcript, const uint64_t *modulus,
+                          uint32_t limbs, int32_t device, int32_t with_pcs, uint64_t *msgs1_out, uint64_t *msgs2_out,
+                          uint64_t *v_s_out, uint64_t *r_y_out, zinc_zip_proof **zip_proof_out) {
+    if (!constraints || !s_masks || !c || !transcript || !msgs1_out || !msgs2_out || !v_s_out || !r_y_out ||
+        (l && !public_input) || (w_len && !w_ccs) || (with_pcs && !zip_proof_out))
+        return ZINC_ERR_NULL;
+    if (zip_proof_out) *zip_proof_out = nullptr;
+    return guarded([&] {
+        const FieldConfig f = FieldConfig::make(modulus, limbs);
+        zinc::ccs::CCS_Z ccs;
+        ccs.m = ccs.n = (size_t)1 << s;
+        ccs.s = ccs.s_prime = s;
+        ccs.l = l;
+        ccs.t = t;
+        ccs.q = q;
+        ccs.d = d;
+        for (uint32_t i = 0; i < q; i++) {
+            ccs.c.push_back(c[i]);
+            ccs.S.emplace_back();
+            for (uint32_t j = 0; j < 32; j++)
+                if ((s_masks[i] >> j) & 1u) ccs.S.back().push_back(j);
+        }
+        zinc::ccs::Statement_Z st;
+        for (uint32_t k = 0; k < t; k++) {
+            const zip_sparse_matrix &M = constraints[k];
+            zinc::ccs::SparseMatrix m;
+            m.n_rows = M.n_rows;
+            m.n_cols = M.n_cols;
+            m.row_ptr.assign(M.row_ptr, M.row_ptr + M.n_rows + 1);
+            m.col_idx.assign(M.col_idx, M.col_idx + M.row_ptr[M.n_rows]);
+            m.values.assign(M.values, M.values + M.row_ptr[M.n_rows]);
+            st.constraints.push_back(std::move(m));
+        }
+        st.public_input.assign(public_input, public_input + l);
+        zinc::ccs::Witness_Z wit;
+        wit.w_ccs.assign(w_ccs, w_ccs + w_len);
+        const zinc::ZincProver prover(LinearCodeSpec{}, device);
+        zinc::SpartanProof sp;
+        std::vector<Limbs> r_y;
+        if (with_pcs) {
+            // Prover::prove; r_y is recomputed from the proof by the verifier, returned here for the tests
+            zinc::KeccakTranscript probe = transcript->t;
+            auto proof = prover.prove(st, wit, transcript->t, ccs, f);
+            r_y = prover.spartan_prove(st, zinc::ZincProver::get_z_ccs(st, wit, ccs), probe, ccs, f).second;
+            sp = std::move(proof.spartan_proof);
+            *zip_proof_out = new zinc_zip_proof{std::move(proof.zip_proof), limbs};
+        } else {
+            auto res = prover.spartan_prove(st, zinc::ZincProver::get_z_ccs(st, wit, ccs), transcript->t, ccs, f);
+            sp = std::move(res.first);
+            r_y = std::move(res.second);
+        }
+        auto put = [&](uint64_t *dst, const Limbs &v) {
+            for (uint32_t i = 0; i < limbs; i++) dst[i] = v[i];
+        };
+        for (size_t r = 0; r < sp.linearization_sumcheck.msgs.size(); r++)
+            for (uint32_t e = 0; e <= d + 1; e++) put(msgs1_out + (r * (d + 2) + e) * limbs, sp.linearization_sumcheck.msgs[r][e]);
+        for (size_t r = 0; r < sp.second_sumcheck.msgs.size(); r++)
+            for (uint32_t e = 0; e < 3; e++) put(msgs2_out + (r * 3 + e) * limbs, sp.second_sumcheck.msgs[r][e]);
+        for (size_t k = 0; k < sp.V_s.size(); k++) put(v_s_out + k * limbs, sp.V_s[k]);
+        for (size_t i = 0; i < r_y.size(); i++) put(r_y_out + i * limbs, r_y[i]);
+    });
+}
+
 }  // extern "C"

@@ -791,7 +791,8 @@ zip::ZipProof zip::commit_z_mle_and_prove_evaluation(const LinearCodeSpec &lc_sp
 namespace {
 sumcheck::ProverOutput prove_as_subprotocol_impl(KeccakTranscript &transcript, const std::vector<const uint64_t *> &mles,
                                                  uint32_t nvars, uint32_t degree, const zip_sumcheck_comb *comb,
-                                                 const FieldConfig &config, int device) {
+                                                 const FieldConfig &config, int device,
+                                                 zip_mem_kind kind = ZIP_MEM_HOST) {
     // sumcheck.rs:64-76 (FIELD_LIMBS > 1: the u128 map)
     transcript.absorb_random_field(config, map_to_field_u128(config, nvars, 0));
     transcript.absorb_random_field(config, map_to_field_u128(config, degree, 0));
@@ -799,7 +800,7 @@ sumcheck::ProverOutput prove_as_subprotocol_impl(KeccakTranscript &transcript, c
     if (nvars == 0) return out;  // :77-92: empty proof
     const zip_field zf = config.to_abi();
     zip_sumcheck *raw = nullptr;
-    int32_t rc = zip_sumcheck_init(device, mles.data(), ZIP_MEM_HOST, (uint32_t)mles.size(), nvars, degree, comb, &zf, &raw);
+    int32_t rc = zip_sumcheck_init(device, mles.data(), kind, (uint32_t)mles.size(), nvars, degree, comb, &zf, &raw);
     if (rc) throw ZipError(rc == ZIP_ERR_INVALID_PARAM ? ZipError::InvalidPcsParam : ZipError::Device,
                            std::string("zip_sumcheck_init: ") + zip_strerror(rc));
     std::unique_ptr<zip_sumcheck, void (*)(zip_sumcheck *)> s(raw, zip_sumcheck_free);
@@ -828,11 +829,9 @@ sumcheck::ProverOutput sumcheck::prove_as_subprotocol_product(KeccakTranscript &
     return prove_as_subprotocol_impl(transcript, mles, nvars, degree, nullptr, config, device);
 }
 
-sumcheck::ProverOutput sumcheck::prove_as_subprotocol_ccs(KeccakTranscript &transcript,
-                                                          const std::vector<const uint64_t *> &mles, uint32_t nvars,
-                                                          uint32_t degree, const std::vector<Limbs> &c,
-                                                          const std::vector<std::vector<uint32_t>> &S,
-                                                          const FieldConfig &config, int device) {
+namespace {
+zip_sumcheck_comb make_comb(size_t n_mles, const std::vector<Limbs> &c, const std::vector<std::vector<uint32_t>> &S,
+                            const FieldConfig &config) {
     if (c.size() != S.size()) throw std::logic_error("ccs.c and ccs.S differ in length");
     zip_sumcheck_comb comb{};
     for (size_t t = 0; t < c.size(); t++) {
@@ -841,14 +840,161 @@ sumcheck::ProverOutput sumcheck::prove_as_subprotocol_ccs(KeccakTranscript &tran
         if (zero) continue;
         if (comb.n_terms == 8) throw ZipError(ZipError::InvalidPcsParam, "more than 8 non-zero CCS terms");
         for (uint32_t j : S[t]) {
-            if (j >= mles.size()) throw std::logic_error("index out of bounds: ccs.S refers to a missing MLE");
+            if (j >= n_mles) throw std::logic_error("index out of bounds: ccs.S refers to a missing MLE");
             comb.term_mask[comb.n_terms] |= 1u << j;
         }
         for (uint32_t i = 0; i < config.limbs; i++) comb.coeff[comb.n_terms][i] = c[t][i];
         comb.n_terms++;
     }
     if (comb.n_terms == 0) throw ZipError(ZipError::InvalidPcsParam, "no non-zero CCS term");
+    return comb;
+}
+}  // namespace
+
+sumcheck::ProverOutput sumcheck::prove_as_subprotocol_ccs(KeccakTranscript &transcript,
+                                                          const std::vector<const uint64_t *> &mles, uint32_t nvars,
+                                                          uint32_t degree, const std::vector<Limbs> &c,
+                                                          const std::vector<std::vector<uint32_t>> &S,
+                                                          const FieldConfig &config, int device) {
+    const zip_sumcheck_comb comb = make_comb(mles.size(), c, S, config);
     return prove_as_subprotocol_impl(transcript, mles, nvars, degree, &comb, config, device);
+}
+
+// ---------------------------------------------------------------------------- CCS
+ccs::SparseMatrix ccs::SparseMatrix::from_coeffs(uint32_t n_rows, uint32_t n_cols,
+                                                 const std::vector<std::vector<std::pair<int64_t, uint32_t>>> &coeffs) {
+    if (coeffs.size() > n_rows) throw std::logic_error("more coefficient rows than n_rows");
+    SparseMatrix M;
+    M.n_rows = n_rows;
+    M.n_cols = n_cols;
+    M.row_ptr.assign(1, 0);
+    for (uint32_t r = 0; r < n_rows; r++) {
+        if (r < coeffs.size())
+            for (const auto &[v, col] : coeffs[r]) {
+                M.values.push_back(v);
+                M.col_idx.push_back(col);
+            }
+        M.row_ptr.push_back((uint32_t)M.col_idx.size());
+    }
+    return M;
+}
+
+std::vector<int64_t> ccs::Statement_Z::get_z_vector(const std::vector<int64_t> &w) const {
+    std::vector<int64_t> z;
+    z.reserve(public_input.size() + w.size() + 1);
+    z.insert(z.end(), public_input.begin(), public_input.end());
+    z.push_back(1);
+    z.insert(z.end(), w.begin(), w.end());
+    return z;
+}
+
+// ---------------------------------------------------------------------------- ZincProver
+std::vector<int64_t> ZincProver::get_z_ccs(const ccs::Statement_Z &statement, const ccs::Witness_Z &wit,
+                                           const ccs::CCS_Z &ccs) {
+    std::vector<int64_t> z = statement.get_z_vector(wit.w_ccs);
+    if (z.size() <= ccs.m) z.resize(ccs.m, 0);  // prover.rs:230-232
+    return z;
+}
+
+namespace {
+struct CcsHandle {
+    zip_ccs *h = nullptr;
+    ~CcsHandle() { zip_ccs_free(h); }
+    void check(int32_t rc, const char *what) const {
+        if (rc == ZIP_OK) return;
+        const std::string msg = std::string(what) + ": " + (h ? zip_ccs_last_error(h) : zip_strerror(rc));
+        if (rc == ZIP_ERR_SHAPE) throw std::logic_error(msg);  // the reference panics / LengthsNotEqual
+        throw ZipError(rc == ZIP_ERR_INVALID_PARAM ? ZipError::InvalidPcsParam : ZipError::Device, msg);
+    }
+    const uint64_t *table(zip_ccs_table_kind which, uint32_t index) const {
+        const uint64_t *p = nullptr;
+        check(zip_ccs_table(h, which, index, &p), "zip_ccs_table");
+        return p;
+    }
+};
+}  // namespace
+
+std::pair<SpartanProof, std::vector<Limbs>> ZincProver::spartan_prove(const ccs::Statement_Z &statement,
+                                                                      const std::vector<int64_t> &z_ccs,
+                                                                      KeccakTranscript &transcript, const ccs::CCS_Z &ccs,
+                                                                      const FieldConfig &config) const {
+    // the shape the reference's prover supports (see the header)
+    if (ccs.s == 0 || ccs.s > 28 || ccs.m != ((size_t)1 << ccs.s) || ccs.n != ccs.m || ccs.s_prime != ccs.s)
+        throw std::logic_error("assertion failed: rx.len() == num_rows (compute_eval_table_sparse): m == n == 2^s is required");
+    if (statement.constraints.size() != ccs.t || ccs.S.size() != ccs.q || ccs.c.size() != ccs.q)
+        throw std::logic_error("CCS sizes and the statement disagree");
+    if (z_ccs.size() > ccs.m) throw std::logic_error("LengthsNotEqual: M.n_cols != z.len()");
+    std::vector<std::vector<uint32_t>> S(ccs.q);
+    {
+        size_t pos = 0;
+        for (size_t i = 0; i < ccs.q; i++) {
+            if (ccs.c[i] == 0) throw ZipError(ZipError::InvalidPcsParam, "a zero CCS coefficient shifts the MLE list the combination function indexes");
+            for (size_t j : ccs.S[i]) {
+                if (j != pos++) throw ZipError(ZipError::InvalidPcsParam, "ccs.S must list the matrices 0..t-1 in order");
+                S[i].push_back((uint32_t)j);
+            }
+        }
+        if (pos != ccs.t) throw ZipError(ZipError::InvalidPcsParam, "ccs.S must list the matrices 0..t-1 in order");
+    }
+    const zip_field zf = config.to_abi();
+    const uint32_t s = (uint32_t)ccs.s, t = (uint32_t)ccs.t;
+    std::vector<zip_sparse_matrix> mats;
+    for (const auto &M : statement.constraints) mats.push_back(M.to_abi());
+    CcsHandle dev;
+    dev.check(zip_ccs_create(device_, mats.data(), t, s, &zf, &dev.h), "zip_ccs_create");
+    // prepare_for_random_field_piop: z_ccs -> F_q; calculate_Mz_mles
+    dev.check(zip_ccs_set_z(dev.h, z_ccs.data(), z_ccs.size(), ZIP_MEM_HOST), "zip_ccs_set_z");
+
+    SpartanProof proof;
+    // ---- sumcheck_1 (prover.rs:242-259)
+    transcript.absorb(reinterpret_cast<const uint8_t *>("beta_s"), 6);  // squeeze_beta_challenges, zinc/utils.rs:100-106
+    std::vector<uint64_t> flat((size_t)s * config.limbs);
+    for (uint32_t i = 0; i < s; i++) {
+        const Limbs b = transcript.get_challenge(config);
+        std::copy(b.begin(), b.begin() + config.limbs, flat.begin() + (size_t)i * config.limbs);
+    }
+    dev.check(zip_ccs_eq_table(dev.h, flat.data(), 0), "zip_ccs_eq_table");
+    std::vector<const uint64_t *> g;  // prepare_lin_sumcheck_polynomial: [Mz_0 .. Mz_{t-1}, eq(beta)], degree d + 1
+    for (uint32_t k = 0; k < t; k++) g.push_back(dev.table(ZIP_CCS_MZ, k));
+    g.push_back(dev.table(ZIP_CCS_EQ, 0));
+    std::vector<Limbs> c_f;
+    for (int64_t c : ccs.c) c_f.push_back(map_to_field(config, c));  // CCS_Z::map_to_field, ccs_z.rs:147
+    const zip_sumcheck_comb comb = make_comb(g.size(), c_f, S, config);
+    auto sc1 = prove_as_subprotocol_impl(transcript, g, s, (uint32_t)ccs.d + 1, &comb, config, device_, ZIP_MEM_DEVICE);
+    proof.linearization_sumcheck = std::move(sc1.proof);
+    const std::vector<Limbs> &r_x = sc1.randomness;
+
+    // ---- sumcheck_2 (prover.rs:261-303)
+    transcript.absorb(reinterpret_cast<const uint8_t *>("gamma"), 5);  // squeeze_gamma_challenge, zinc/utils.rs:112-118
+    const Limbs gamma = transcript.get_challenge(config);
+    for (uint32_t i = 0; i < s; i++) std::copy(r_x[i].begin(), r_x[i].begin() + config.limbs, flat.begin() + (size_t)i * config.limbs);
+    std::vector<uint64_t> vs((size_t)t * config.limbs);
+    dev.check(zip_ccs_second_table(dev.h, flat.data(), gamma.data(), vs.data()), "zip_ccs_second_table");
+    const std::vector<const uint64_t *> two{dev.table(ZIP_CCS_SECOND, 0), dev.table(ZIP_CCS_Z_FIELD, 0)};
+    auto sc2 = prove_as_subprotocol_impl(transcript, two, s, 2, nullptr, config, device_, ZIP_MEM_DEVICE);
+    proof.second_sumcheck = std::move(sc2.proof);
+
+    // ---- calculate_V_s (prover.rs:330-347), computed with the second table
+    for (uint32_t k = 0; k < t; k++) {
+        Limbs v{};
+        for (uint32_t i = 0; i < config.limbs; i++) v[i] = vs[(size_t)k * config.limbs + i];
+        proof.V_s.push_back(v);
+    }
+    return {std::move(proof), std::move(sc2.randomness)};
+}
+
+ZincProof ZincProver::prove(const ccs::Statement_Z &statement, const ccs::Witness_Z &wit, KeccakTranscript &transcript,
+                            const ccs::CCS_Z &ccs, const FieldConfig &config) const {
+    const std::vector<int64_t> z_ccs = get_z_ccs(statement, wit, ccs);
+    auto [spartan_proof, r_y] = spartan_prove(statement, z_ccs, transcript, ccs, config);
+    // commit_z_mle_and_prove_evaluation (prover.rs:305-327); z_mle = from_evaluations_slice(s_prime, z_ccs)
+    std::vector<int64_t> z_mle(z_ccs);
+    z_mle.resize((size_t)1 << ccs.s_prime, 0);
+    ZincProof out;
+    out.spartan_proof = std::move(spartan_proof);
+    out.zip_proof = zip::commit_z_mle_and_prove_evaluation(lc_spec_, z_mle.data(), ccs.m, r_y.data(), r_y.size(), transcript,
+                                                           config, device_);
+    return out;
 }
 
 }  // namespace zinc

@@ -269,4 +269,65 @@ ProverOutput prove_as_subprotocol_ccs(KeccakTranscript &transcript, const std::v
                                       const std::vector<std::vector<uint32_t>> &S, const FieldConfig &config,
                                       int device = 0);
 }  // namespace sumcheck
+
+// ---------------------------------------------------------------------------- CCS (src/ccs/ccs_z.rs)
+namespace ccs {
+// SparseMatrix<Int<1>> (src/sparse_matrix.rs:12-17) as CSR; `coeffs` may hold fewer than n_rows rows
+// (pad_rows only bumps n_rows, :104-108): from_coeffs() leaves the missing rows empty.
+struct SparseMatrix {
+    uint32_t n_rows = 0, n_cols = 0;
+    std::vector<uint32_t> row_ptr{0}, col_idx;
+    std::vector<int64_t> values;
+    static SparseMatrix from_coeffs(uint32_t n_rows, uint32_t n_cols,
+                                    const std::vector<std::vector<std::pair<int64_t, uint32_t>>> &coeffs);
+    zip_sparse_matrix to_abi() const { return {n_rows, n_cols, row_ptr.data(), col_idx.data(), values.data()}; }
+};
+struct CCS_Z {  // src/ccs/ccs_z.rs:30-52
+    size_t m = 0, n = 0, l = 0, t = 0, q = 0, d = 0, s = 0, s_prime = 0;
+    std::vector<std::vector<size_t>> S;
+    std::vector<int64_t> c;
+};
+struct Statement_Z {  // :155-158
+    std::vector<SparseMatrix> constraints;
+    std::vector<int64_t> public_input;
+    std::vector<int64_t> get_z_vector(const std::vector<int64_t> &w) const;  // x || 1 || w, :219-229
+};
+struct Witness_Z {  // :178-182
+    std::vector<int64_t> w_ccs;
+};
+}  // namespace ccs
+
+// ---------------------------------------------------------------------------- ZincProver (src/zinc/prover.rs)
+// SpartanProof / ZincProof (src/zinc/structs.rs:13-30)
+struct SpartanProof {
+    sumcheck::SumcheckProof linearization_sumcheck, second_sumcheck;
+    std::vector<Limbs> V_s;
+};
+struct ZincProof {
+    SpartanProof spartan_proof;
+    zip::ZipProof zip_proof;
+};
+// The transcript, the challenges and the proof objects live here; every O(n) loop runs on the device
+// (zip_ccs_* for the matrix / eq tables, zip_sumcheck_* for the rounds, the Zip PCS for the last step).
+// Shape: m == n == 2^s == 2^s_prime, every c[i] != 0, the S[i] concatenated == 0..t-1 -- what the
+// reference's own code supports (compute_eval_table_sparse asserts rx.len() == ccs.n, ccs_f.rs:133;
+// sumcheck_polynomial_comb_fn_1 indexes the MLE list by matrix number, zinc/utils.rs:84-88);
+// anything else throws std::logic_error where the reference panics.
+class ZincProver {
+  public:
+    explicit ZincProver(zip::LinearCodeSpec spec = {}, int device = 0) : lc_spec_(spec), device_(device) {}
+    // Prover::prove (prover.rs:50-88)
+    ZincProof prove(const ccs::Statement_Z &statement, const ccs::Witness_Z &wit, KeccakTranscript &transcript,
+                    const ccs::CCS_Z &ccs, const FieldConfig &config) const;
+    // prepare_for_random_field_piop (:172-191, the z vector) + SpartanProver::prove (:130-161)
+    std::pair<SpartanProof, std::vector<Limbs>> spartan_prove(const ccs::Statement_Z &statement, const std::vector<int64_t> &z_ccs,
+                                                              KeccakTranscript &transcript, const ccs::CCS_Z &ccs,
+                                                              const FieldConfig &config) const;
+    // get_z_ccs_and_z_mle (:222-239): x || 1 || w, zero-extended to ccs.m
+    static std::vector<int64_t> get_z_ccs(const ccs::Statement_Z &statement, const ccs::Witness_Z &wit, const ccs::CCS_Z &ccs);
+
+  private:
+    zip::LinearCodeSpec lc_spec_;
+    int device_;
+};
 }  // namespace zinc

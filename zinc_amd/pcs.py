@@ -22,6 +22,7 @@ EXPORTED_SYMBOLS = (
     "zinc_pcs_transcript_probe", "zinc_zip_open", "zinc_pcs_transcript_from_proof", "zinc_pcs_transcript_position",
     "zinc_zip_verify", "zinc_zip_evaluate", "zinc_commit_z_mle_and_prove_evaluation", "zinc_zip_proof_len",
     "zinc_zip_proof_num_roots", "zinc_zip_proof_read", "zinc_zip_proof_free", "zinc_zip_release_cached_contexts", "zinc_sumcheck_prove_product", "zinc_sumcheck_prove_ccs", "zinc_zip_data_download", "zinc_zip_data_upload", "zinc_merkle_tree_new",
+    "zinc_prover_prove",
 )
 
 
@@ -106,6 +107,8 @@ def lib():
         L.zinc_zip_data_upload.argtypes = [vp, vp, vp, vp, C.POINTER(vp)]
         L.zinc_merkle_tree_new.argtypes = [C.c_uint32, vp, C.c_size_t, C.c_uint32, C.c_int32, vp]
         L.zinc_sumcheck_prove_product.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_int32, vp, vp]
+        L.zinc_prover_prove.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_size_t, vp,
+                                        C.c_size_t, vp, vp, C.c_uint32, C.c_int32, C.c_int32, vp, vp, vp, vp, C.POINTER(vp)]
         _lib = L
     return _lib
 
@@ -423,3 +426,50 @@ def sumcheck_prove_ccs(transcript: KeccakTranscript, mles, degree: int, c, S, fi
     _check(lib().zinc_sumcheck_prove_ccs(transcript._h, ptrs, K, nv, degree, len(S), cv.ctypes.data, masks.ctypes.data,
                                          field._m.ctypes.data, fl, device, msgs.ctypes.data, rand.ctypes.data))
     return msgs, rand
+
+
+class ZincProver:
+    """ZincProver (src/zinc/structs.rs:33-47, src/zinc/prover.rs).  A CCS is given as
+      matrices  Statement_Z.constraints: objects with n_rows, n_cols, row_ptr, col_idx (uint32), values (int64)  [CSR]
+      s, d, S, c  CCS_Z with m = n = 2^s = 2^s_prime
+      public_input, w_ccs  Statement_Z.public_input, Witness_Z.w_ccs (z = x || 1 || w)"""
+
+    def __init__(self, device: int = 0):
+        self.device = device
+
+    def _run(self, matrices, s, d, S, c, public_input, w_ccs, transcript, field, with_pcs):
+        t, fl = len(matrices), field.limbs
+        keep = [(np.ascontiguousarray(M.row_ptr, dtype=np.uint32), np.ascontiguousarray(M.col_idx, dtype=np.uint32),
+                 np.ascontiguousarray(M.values, dtype=np.int64)) for M in matrices]
+        arr = (cabi.SparseMatrix * t)()
+        for k, (M, (rp, ci, va)) in enumerate(zip(matrices, keep)):
+            arr[k] = cabi.SparseMatrix(M.n_rows, M.n_cols, rp.ctypes.data, ci.ctypes.data, va.ctypes.data)
+        masks = np.array([sum(1 << j for j in Si) for Si in S], dtype=np.uint32)
+        cv = np.array(c, dtype=np.int64)
+        x = np.ascontiguousarray(public_input, dtype=np.int64)
+        w = np.ascontiguousarray(w_ccs, dtype=np.int64)
+        out = dict(msgs1=np.zeros((s, d + 2, fl), np.uint64), msgs2=np.zeros((s, 3, fl), np.uint64),
+                   V_s=np.zeros((t, fl), np.uint64), r_y=np.zeros((s, fl), np.uint64))
+        h = C.c_void_p()
+        _check(lib().zinc_prover_prove(arr, t, s, d, len(S), masks.ctypes.data, cv.ctypes.data, x.ctypes.data, x.size,
+                                       w.ctypes.data, w.size, transcript._h, field._m.ctypes.data, fl, self.device,
+                                       1 if with_pcs else 0, out["msgs1"].ctypes.data, out["msgs2"].ctypes.data,
+                                       out["V_s"].ctypes.data, out["r_y"].ctypes.data, C.byref(h)))
+        if with_pcs:
+            try:
+                roots = np.zeros((lib().zinc_zip_proof_num_roots(h), 32), np.uint8)
+                v = np.zeros(fl, np.uint64)
+                proof = np.zeros(lib().zinc_zip_proof_len(h), np.uint8)
+                lib().zinc_zip_proof_read(h, roots.ctypes.data, v.ctypes.data, proof.ctypes.data)
+            finally:
+                lib().zinc_zip_proof_free(h)
+            out["zip_proof"] = dict(z_comm=roots, v=v, pcs_proof=proof)
+        return out
+
+    def spartan_prove(self, matrices, s, d, S, c, public_input, w_ccs, transcript: KeccakTranscript, field: FieldConfig):
+        """prepare_for_random_field_piop + SpartanProver::prove (prover.rs:130-161) -> SpartanProof fields + r_y."""
+        return self._run(matrices, s, d, S, c, public_input, w_ccs, transcript, field, False)
+
+    def prove(self, matrices, s, d, S, c, public_input, w_ccs, transcript: KeccakTranscript, field: FieldConfig):
+        """Prover::prove (prover.rs:50-88) -> ZincProof {spartan_proof, zip_proof}."""
+        return self._run(matrices, s, d, S, c, public_input, w_ccs, transcript, field, True)
