@@ -142,12 +142,22 @@ int32_t zinc_sumcheck_prove_ccs(zinc_transcript *transcript, const uint64_t *con
  *   public_input / w_ccs   Statement_Z.public_input (l entries), Witness_Z.w_ccs: z = x || 1 || w
  *   outputs       SpartanProof.linearization_sumcheck: s * (d + 2) elements; .second_sumcheck: s * 3;
  *                 .V_s: t; r_y: s elements (all Montgomery limbs); ZipProof through the last argument when with_pcs != 0
- * ZINC_ERR_PANIC where the reference panics (shapes the prover's own assertions reject). */
+ * ZINC_ERR_PANIC where the reference panics (shapes the prover's own assertions reject).
+ *
+ * zinc_prover_prepare: the circuit's matrices mapped to F_q and resident in HBM (what
+ * prepare_for_random_field_piop recomputes per proof, prover.rs:188-189, depends only on circuit and field).
+ * Pass the handle as `prepared` (then `constraints` may be NULL) to every proof of that circuit; NULL = build
+ * and drop it inside the call, as the reference does. */
+typedef struct zinc_prepared_ccs zinc_prepared_ccs;
+int32_t zinc_prover_prepare(const zip_sparse_matrix *constraints, uint32_t t, uint32_t s, const uint64_t *modulus,
+                            uint32_t limbs, int32_t device, zinc_prepared_ccs **out);
+void zinc_prepared_ccs_free(zinc_prepared_ccs *p);
 int32_t zinc_prover_prove(const zip_sparse_matrix *constraints, uint32_t t, uint32_t s, uint32_t d, uint32_t q,
                           const uint32_t *s_masks, const int64_t *c, const int64_t *public_input, size_t l,
                           const int64_t *w_ccs, size_t w_len, zinc_transcript *transcript, const uint64_t *modulus,
-                          uint32_t limbs, int32_t device, int32_t with_pcs, uint64_t *msgs1_out, uint64_t *msgs2_out,
-                          uint64_t *v_s_out, uint64_t *r_y_out, zinc_zip_proof **zip_proof_out);
+                          uint32_t limbs, int32_t device, zinc_prepared_ccs *prepared, int32_t with_pcs,
+                          uint64_t *msgs1_out, uint64_t *msgs2_out, uint64_t *v_s_out, uint64_t *r_y_out,
+                          zinc_zip_proof **zip_proof_out);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,9 @@ int32_t zip_abi_version(void);
 const char *zip_strerror(int32_t code);
 /* number of visible HIP devices (0 when there is no GPU); never initialises a context */
 int32_t zip_device_count(void);
+/* zip_sumcheck / zip_ccs handles live for one proof; their device blocks are kept (per device, at most 4 GiB)
+ * for the next handle instead of going back to hipFree / hipMalloc.  This returns them to the driver. */
+void zip_release_cached_memory(void);
 
 /* Threading: calls on one ctx (and on its commitments) are serialised inside the library -- they
  * share one pinned staging buffer and one set of streams; distinct contexts run concurrently. */

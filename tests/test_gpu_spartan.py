@@ -170,3 +170,41 @@ def test_zinc_prove_end_to_end(mods, q, fl, log_n):
     wrong = zp["v"].copy()
     wrong[0] ^= np.uint64(1)
     assert o.final_check(f, pts, wrong) == orc.ORC_ERR_PROOF
+
+
+def test_prepared_circuit_is_reused_across_proofs(mods):
+    """PreparedCcs: the matrices stay on the device; proofs for different witnesses of the circuit equal the
+    unprepared ones (and the oracle's)."""
+    _, pcs = mods
+    field = pcs.FieldConfig(QSTARK, 4)
+    f = orc.make_field(QSTARK, 4)
+    prover = pcs.ZincProver()
+    base = _ccs.vitalik_ccs(3)
+    prep = prover.prepare(base.matrices, base.s, field)
+    for x in (3, 5, -7):
+        inst = _ccs.vitalik_ccs(x)
+        want = orc.Ccs(inst).spartan_prove(f, orc.new_transcript())
+        got = prover.spartan_prove(inst.matrices, inst.s, inst.d, inst.S, inst.c, inst.z[:1], inst.z[2:],
+                                   pcs.KeccakTranscript(), field, prepared=prep)
+        for key in ("msgs1", "msgs2", "V_s", "r_y"):
+            assert np.array_equal(got[key], want[key]), (x, key)
+    other = pcs.FieldConfig(Q192, 3)
+    with pytest.raises(pcs.ReferencePanic):
+        prover.spartan_prove(base.matrices, base.s, base.d, base.S, base.c, base.z[:1], base.z[2:],
+                             pcs.KeccakTranscript(), other, prepared=prep)
+
+
+def test_ccs_tables_at_2_pow_20(mods):
+    """MiB-sized index arrays whose byte length is not a multiple of the copy threads (row_ptr has 2^20 + 1 entries):
+    the last row of M z depends on the last word of row_ptr."""
+    cabi, _ = mods
+    inst = _ccs.dummy_ccs_from_len(1 << 20, seed=20)
+    f = orc.make_field(QSTARK, 4)
+    want = orc.Ccs(inst).mz(f)
+    for rep in range(2):  # the second handle runs on recycled device blocks and pinned buffers
+        d = cabi.Ccs(inst.matrices, inst.s, cabi.make_field(QSTARK, 4))
+        d.set_z(inst.z)
+        for k in range(inst.t):
+            assert np.array_equal(d.download(cabi.CCS_MZ, k), want[k]), (rep, k)
+        d.free()
+    cabi.lib().zip_release_cached_memory()

@@ -5,6 +5,7 @@
 // HIP-event measurement hooks used by bench.py.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <thread>
 
 #include <cstdarg>
@@ -69,6 +70,10 @@ struct zip_ctx {
     unsigned char *bounce[2] = {nullptr, nullptr};
     size_t bounce_cap = 0;
     std::string last_error;
+    // private plumbing context of a zip_sumcheck / zip_ccs: its blocks go to the process-wide recycle bin
+    // when it dies and are taken from there first (these handles live for one proof, hipMalloc is ~ms)
+    bool recycle = false;
+    size_t h2d_bounce_threshold = (size_t)8 << 20;  // below: plain hipMemcpyAsync from the caller's (pageable) memory
     // caching allocator: exact-size free lists
     std::multimap<size_t, void *> free_blocks;
     std::map<void *, size_t> live_blocks;
@@ -152,6 +157,56 @@ int32_t fail(zip_ctx *ctx, int32_t code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                    \
     } while (0)
 
+// Device blocks of dead short-lived contexts (ctx->recycle), per device, exact-size lists.  A block enters
+// only after its context synchronised every stream it had, so the next owner may use it at once.
+struct RecycleBin {
+    std::mutex mu;
+    std::multimap<size_t, void *> blocks;
+    size_t bytes = 0;
+    unsigned char *bounce[2] = {nullptr, nullptr};  // one spare pair of pinned bounce buffers (hipHostMalloc is ~10 ms)
+    size_t bounce_cap = 0;
+};
+constexpr int kMaxDevices = 16;
+constexpr size_t kRecycleCapBytes = (size_t)4 << 30;
+RecycleBin g_recycle[kMaxDevices];
+
+void *recycle_take(int device, size_t bytes) {
+    if (device < 0 || device >= kMaxDevices) return nullptr;
+    RecycleBin &bin = g_recycle[device];
+    std::lock_guard<std::mutex> g(bin.mu);
+    auto it = bin.blocks.find(bytes);
+    if (it == bin.blocks.end()) return nullptr;
+    void *p = it->second;
+    bin.blocks.erase(it);
+    bin.bytes -= bytes;
+    return p;
+}
+void recycle_give(int device, size_t bytes, void *p) {
+    if (device >= 0 && device < kMaxDevices) {
+        RecycleBin &bin = g_recycle[device];
+        std::lock_guard<std::mutex> g(bin.mu);
+        if (bin.bytes + bytes <= kRecycleCapBytes) {
+            bin.blocks.emplace(bytes, p);
+            bin.bytes += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+void recycle_flush(int device) {
+    if (device < 0 || device >= kMaxDevices) return;
+    RecycleBin &bin = g_recycle[device];
+    std::lock_guard<std::mutex> g(bin.mu);
+    for (auto &kv : bin.blocks) (void)hipFree(kv.second);
+    bin.blocks.clear();
+    bin.bytes = 0;
+    for (auto *&b : bin.bounce) {
+        if (b) (void)hipHostFree(b);
+        b = nullptr;
+    }
+    bin.bounce_cap = 0;
+}
+
 int32_t pool_alloc(zip_ctx *ctx, size_t bytes, void **out) {
     *out = nullptr;
     if (bytes == 0) bytes = 16;
@@ -160,12 +215,14 @@ int32_t pool_alloc(zip_ctx *ctx, size_t bytes, void **out) {
     if (it != ctx->free_blocks.end()) {
         *out = it->second;
         ctx->free_blocks.erase(it);
+    } else if (ctx->recycle && (*out = recycle_take(ctx->device, bytes))) {
     } else {
         hipError_t e = hipMalloc(out, bytes);
         if (e != hipSuccess) {
             // release cached blocks and retry once
             for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
             ctx->free_blocks.clear();
+            recycle_flush(ctx->device);
             e = hipMalloc(out, bytes);
             if (e != hipSuccess)
                 return fail(ctx, ZIP_ERR_ALLOC, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
@@ -289,6 +346,19 @@ constexpr size_t kBounceThreshold = (size_t)8 << 20;
 
 int32_t ensure_bounce(zip_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->bounce_cap) return ZIP_OK;
+    if (ctx->recycle && !ctx->bounce[0] && ctx->device >= 0 && ctx->device < kMaxDevices) {
+        RecycleBin &bin = g_recycle[ctx->device];
+        std::lock_guard<std::mutex> g(bin.mu);
+        if (bin.bounce_cap >= bytes) {
+            for (int i = 0; i < 2; i++) {
+                ctx->bounce[i] = bin.bounce[i];
+                bin.bounce[i] = nullptr;
+            }
+            ctx->bounce_cap = bin.bounce_cap;
+            bin.bounce_cap = 0;
+            return ZIP_OK;
+        }
+    }
     for (auto *&b : ctx->bounce) {
         if (b) (void)hipHostFree(b);
         b = nullptr;
@@ -309,7 +379,7 @@ void parallel_memcpy(void *dst, const void *src, size_t bytes) {
     }
     unsigned n = std::thread::hardware_concurrency();
     n = n ? std::min(n, 8u) : 4u;
-    const size_t per = ((bytes / n) + 4095) & ~(size_t)4095;
+    const size_t per = (((bytes + n - 1) / n) + 4095) & ~(size_t)4095;  // n * per >= bytes (a truncating bytes / n lost a tail of < n bytes)
     std::vector<std::thread> th;
     for (unsigned t = 1; t < n; t++) {
         const size_t lo = (size_t)t * per;
@@ -356,7 +426,7 @@ int32_t copy_d2h_bounced(zip_ctx *ctx, void *dst_h, const void *src_d, size_t by
 // dst_d <- src_h (pageable) on `st`.  Returns once the caller's buffer has been read completely
 // (the last chunk may still be in flight from the bounce buffer; later work on `st` is ordered).
 int32_t copy_h2d_bounced(zip_ctx *ctx, void *dst_d, const void *src_h, size_t bytes, hipStream_t st) {
-    if (bytes < kBounceThreshold) {
+    if (bytes < ctx->h2d_bounce_threshold) {
         HIP_TRY(ctx, hipMemcpyAsync(dst_d, src_h, bytes, hipMemcpyHostToDevice, st));
         return ZIP_OK;
     }
@@ -1104,6 +1174,15 @@ const char *zip_strerror(int32_t code) {
     }
 }
 
+void zip_release_cached_memory(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return;
+    for (int d = 0; d < n && d < kMaxDevices; d++) {
+        if (hipSetDevice(d) != hipSuccess) continue;
+        recycle_flush(d);
+    }
+}
+
 int32_t zip_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1215,8 +1294,13 @@ void zip_ctx_destroy(zip_ctx *ctx) {
     if (ctx->s_upper) (void)hipStreamSynchronize(ctx->s_upper);
     if (ctx->s_aux) (void)hipStreamSynchronize(ctx->s_aux);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
-    for (auto &kv : ctx->live_blocks) (void)hipFree(kv.first);
+    if (ctx->recycle) {
+        for (auto &kv : ctx->free_blocks) recycle_give(ctx->device, kv.first, kv.second);
+        for (auto &kv : ctx->live_blocks) recycle_give(ctx->device, kv.second, kv.first);
+    } else {
+        for (auto &kv : ctx->free_blocks) (void)hipFree(kv.second);
+        for (auto &kv : ctx->live_blocks) (void)hipFree(kv.first);
+    }
     for (auto &pe : ctx->pending) {
         (void)hipEventDestroy(pe.start);
         (void)hipEventDestroy(pe.stop);
@@ -1228,6 +1312,17 @@ void zip_ctx_destroy(zip_ctx *ctx) {
     if (ctx->s_aux) (void)hipStreamDestroy(ctx->s_aux);
     if (ctx->stage_big) (void)hipHostFree(ctx->stage_big);
     if (ctx->pinned_base) (void)hipHostFree(ctx->pinned_base);
+    if (ctx->recycle && ctx->bounce[0] && ctx->bounce[1] && ctx->device >= 0 && ctx->device < kMaxDevices) {
+        RecycleBin &bin = g_recycle[ctx->device];
+        std::lock_guard<std::mutex> g(bin.mu);
+        if (!bin.bounce_cap) {
+            for (int i = 0; i < 2; i++) {
+                bin.bounce[i] = ctx->bounce[i];
+                ctx->bounce[i] = nullptr;
+            }
+            bin.bounce_cap = ctx->bounce_cap;
+        }
+    }
     for (auto *b : ctx->bounce)
         if (b) (void)hipHostFree(b);
     if (ctx->perm1_d) (void)hipFree(ctx->perm1_d);
@@ -1908,6 +2003,7 @@ int32_t zip_sumcheck_init(int32_t device, const uint64_t *const *mles, zip_mem_k
     zip_sumcheck *s = new (std::nothrow) zip_sumcheck();
     if (!ctx || !s) { delete ctx; delete s; return ZIP_ERR_ALLOC; }
     ctx->device = device;
+    ctx->recycle = true;
     s->ctx = ctx;
     int32_t rc = ZIP_OK;
     do {
@@ -2024,6 +2120,8 @@ int32_t zip_ccs_create(int32_t device, const zip_sparse_matrix *mats, uint32_t t
     zip_ccs *c = new (std::nothrow) zip_ccs();
     if (!ctx || !c) { delete ctx; delete c; return ZIP_ERR_ALLOC; }
     ctx->device = device;
+    ctx->recycle = true;
+    ctx->h2d_bounce_threshold = (size_t)256 << 10;  // MiB-sized index arrays: staged pageable copies run at 3-4 GB/s
     c->ctx = ctx;
     int32_t rc = ZIP_OK;
     do {
@@ -2036,19 +2134,28 @@ int32_t zip_ccs_create(int32_t device, const zip_sparse_matrix *mats, uint32_t t
         c->fl = hf.fl;
         memcpy(c->modulus, hf.modulus, sizeof c->modulus);
         const size_t elem = (size_t)hf.fl * 8, tab = (size_t)m * elem;
+        static const bool dbg = getenv("ZIP_HIP_DEBUG_TIMING") != nullptr;
+        std::vector<uint32_t> col_ptr, row_idx, next;  // reused by every matrix (fresh pages fault at ~1 GB/s)
+        std::vector<int64_t> vals_t;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        };
         for (uint32_t k = 0; k < t && rc == ZIP_OK; k++) {
+            const auto t0 = now();
             const zip_sparse_matrix &M = mats[k];
             zip_ccs::Mat &D = c->mat[k];
             const uint32_t nnz = M.row_ptr[M.n_rows];
             D.n_rows = M.n_rows;
             D.nnz = nnz;
             // the transposed form: a counting sort by column (rows stay ascending inside a column)
-            std::vector<uint32_t> col_ptr((size_t)m + 1, 0), row_idx(nnz);
-            std::vector<int64_t> vals_t(nnz);
+            col_ptr.assign((size_t)m + 1, 0);
+            row_idx.resize(nnz);
+            vals_t.resize(nnz);
             for (uint32_t e = 0; e < nnz; e++) col_ptr[M.col_idx[e] + 1]++;
             for (uint32_t col = 0; col < m; col++) col_ptr[col + 1] += col_ptr[col];
             {
-                std::vector<uint32_t> next(col_ptr.begin(), col_ptr.end() - 1);
+                next.assign(col_ptr.begin(), col_ptr.end() - 1);
                 for (uint32_t r = 0; r < M.n_rows; r++)
                     for (uint32_t e = M.row_ptr[r]; e < M.row_ptr[r + 1]; e++) {
                         const uint32_t dst = next[M.col_idx[e]]++;
@@ -2056,6 +2163,7 @@ int32_t zip_ccs_create(int32_t device, const zip_sparse_matrix *mats, uint32_t t
                         vals_t[dst] = M.values[e];
                     }
             }
+            const auto t1 = now();
             void *tmp = nullptr;  // i64 values before the field map
             if ((rc = pool_alloc(ctx, (size_t)(M.n_rows + 1) * 4, (void **)&D.row_ptr))) break;
             if ((rc = pool_alloc(ctx, (size_t)nnz * 4, (void **)&D.col_idx))) break;
@@ -2064,6 +2172,7 @@ int32_t zip_ccs_create(int32_t device, const zip_sparse_matrix *mats, uint32_t t
             if ((rc = pool_alloc(ctx, (size_t)nnz * elem, (void **)&D.vals))) break;
             if ((rc = pool_alloc(ctx, (size_t)nnz * elem, (void **)&D.vals_t))) break;
             if ((rc = pool_alloc(ctx, (size_t)nnz * 8, &tmp))) break;
+            const auto t2 = now();
             if ((rc = copy_h2d_bounced(ctx, D.row_ptr, M.row_ptr, (size_t)(M.n_rows + 1) * 4, ctx->stream))) break;
             if ((rc = copy_h2d_bounced(ctx, D.col_ptr, col_ptr.data(), ((size_t)m + 1) * 4, ctx->stream))) break;
             if (nnz) {
@@ -2081,6 +2190,9 @@ int32_t zip_ccs_create(int32_t device, const zip_sparse_matrix *mats, uint32_t t
             if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
             pool_release(ctx, tmp);
             if ((rc = pool_alloc(ctx, tab, (void **)&c->mz[k]))) break;
+            if (dbg)
+                fprintf(stderr, "[zip_ccs_create] matrix %u: transpose %.2f ms, alloc %.2f ms, upload+map %.2f ms\n", k,
+                        ms(t0, t1), ms(t1, t2), ms(t2, now()));
         }
         if (rc) break;
         if ((rc = pool_alloc(ctx, tab, (void **)&c->z_f))) break;

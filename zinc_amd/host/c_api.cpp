@@ -320,22 +320,61 @@ int32_t zinc_sumcheck_prove_ccs(zinc_transcript *transcript, const uint64_t *con
     });
 }
 
+namespace {
+zinc::ccs::Statement_Z statement_from_abi(const zip_sparse_matrix *constraints, uint32_t t) {
+    zinc::ccs::Statement_Z st;
+    for (uint32_t k = 0; k < t; k++) {
+        const zip_sparse_matrix &M = constraints[k];
+        zinc::ccs::SparseMatrix m;
+        m.n_rows = M.n_rows;
+        m.n_cols = M.n_cols;
+        m.row_ptr.assign(M.row_ptr, M.row_ptr + M.n_rows + 1);
+        m.col_idx.assign(M.col_idx, M.col_idx + M.row_ptr[M.n_rows]);
+        m.values.assign(M.values, M.values + M.row_ptr[M.n_rows]);
+        st.constraints.push_back(std::move(m));
+    }
+    return st;
+}
+zinc::ccs::CCS_Z square_ccs(uint32_t t, uint32_t s) {
+    zinc::ccs::CCS_Z ccs;
+    ccs.m = ccs.n = (size_t)1 << s;
+    ccs.s = ccs.s_prime = s;
+    ccs.t = t;
+    return ccs;
+}
+}  // namespace
+
+struct zinc_prepared_ccs {
+    std::unique_ptr<zinc::PreparedCcs> p;
+    uint32_t t, s;
+};
+
+int32_t zinc_prover_prepare(const zip_sparse_matrix *constraints, uint32_t t, uint32_t s, const uint64_t *modulus,
+                            uint32_t limbs, int32_t device, zinc_prepared_ccs **out) {
+    if (!constraints || !modulus || !out) return ZINC_ERR_NULL;
+    *out = nullptr;
+    return guarded([&] {
+        const FieldConfig f = FieldConfig::make(modulus, limbs);
+        const zinc::ccs::Statement_Z st = statement_from_abi(constraints, t);
+        *out = new zinc_prepared_ccs{std::make_unique<zinc::PreparedCcs>(st, square_ccs(t, s), f, device), t, s};
+    });
+}
+void zinc_prepared_ccs_free(zinc_prepared_ccs *p) { delete p; }
+
 int32_t zinc_prover_prove(const zip_sparse_matrix *constraints, uint32_t t, uint32_t s, uint32_t d, uint32_t q,
                           const uint32_t *s_masks, const int64_t *c, const int64_t *public_input, size_t l,
                           const int64_t *w_ccs, size_t w_len, zinc_transcript *transcript, const uint64_t *modulus,
-                          uint32_t limbs, int32_t device, int32_t with_pcs, uint64_t *msgs1_out, uint64_t *msgs2_out,
-                          uint64_t *v_s_out, uint64_t *r_y_out, zinc_zip_proof **zip_proof_out) {
-    if (!constraints || !s_masks || !c || !transcript || !msgs1_out || !msgs2_out || !v_s_out || !r_y_out ||
+                          uint32_t limbs, int32_t device, zinc_prepared_ccs *prepared, int32_t with_pcs,
+                          uint64_t *msgs1_out, uint64_t *msgs2_out, uint64_t *v_s_out, uint64_t *r_y_out,
+                          zinc_zip_proof **zip_proof_out) {
+    if ((!constraints && !prepared) || !s_masks || !c || !transcript || !msgs1_out || !msgs2_out || !v_s_out || !r_y_out ||
         (l && !public_input) || (w_len && !w_ccs) || (with_pcs && !zip_proof_out))
         return ZINC_ERR_NULL;
     if (zip_proof_out) *zip_proof_out = nullptr;
     return guarded([&] {
         const FieldConfig f = FieldConfig::make(modulus, limbs);
-        zinc::ccs::CCS_Z ccs;
-        ccs.m = ccs.n = (size_t)1 << s;
-        ccs.s = ccs.s_prime = s;
+        zinc::ccs::CCS_Z ccs = square_ccs(t, s);
         ccs.l = l;
-        ccs.t = t;
         ccs.q = q;
         ccs.d = d;
         for (uint32_t i = 0; i < q; i++) {
@@ -345,31 +384,21 @@ int32_t zinc_prover_prove(const zip_sparse_matrix *constraints, uint32_t t, uint
                 if ((s_masks[i] >> j) & 1u) ccs.S.back().push_back(j);
         }
         zinc::ccs::Statement_Z st;
-        for (uint32_t k = 0; k < t; k++) {
-            const zip_sparse_matrix &M = constraints[k];
-            zinc::ccs::SparseMatrix m;
-            m.n_rows = M.n_rows;
-            m.n_cols = M.n_cols;
-            m.row_ptr.assign(M.row_ptr, M.row_ptr + M.n_rows + 1);
-            m.col_idx.assign(M.col_idx, M.col_idx + M.row_ptr[M.n_rows]);
-            m.values.assign(M.values, M.values + M.row_ptr[M.n_rows]);
-            st.constraints.push_back(std::move(m));
-        }
+        if (prepared) st.constraints.resize(t);  // the matrices are on the device already
+        else st = statement_from_abi(constraints, t);
         st.public_input.assign(public_input, public_input + l);
+        zinc::PreparedCcs *prep = prepared ? prepared->p.get() : nullptr;
         zinc::ccs::Witness_Z wit;
         wit.w_ccs.assign(w_ccs, w_ccs + w_len);
         const zinc::ZincProver prover(LinearCodeSpec{}, device);
         zinc::SpartanProof sp;
         std::vector<Limbs> r_y;
         if (with_pcs) {
-            // Prover::prove; r_y is recomputed from the proof by the verifier, returned here for the tests
-            zinc::KeccakTranscript probe = transcript->t;
-            auto proof = prover.prove(st, wit, transcript->t, ccs, f);
-            r_y = prover.spartan_prove(st, zinc::ZincProver::get_z_ccs(st, wit, ccs), probe, ccs, f).second;
+            auto proof = prover.prove(st, wit, transcript->t, ccs, f, &r_y, prep);
             sp = std::move(proof.spartan_proof);
             *zip_proof_out = new zinc_zip_proof{std::move(proof.zip_proof), limbs};
         } else {
-            auto res = prover.spartan_prove(st, zinc::ZincProver::get_z_ccs(st, wit, ccs), transcript->t, ccs, f);
+            auto res = prover.spartan_prove(st, zinc::ZincProver::get_z_ccs(st, wit, ccs), transcript->t, ccs, f, prep);
             sp = std::move(res.first);
             r_y = std::move(res.second);
         }

@@ -2,6 +2,9 @@
 // here; MultilinearZip::commit / open forward every O(n) loop to libzip_hip.so.
 #include "zinc_zip.hpp"
 
+#include <chrono>
+#include <cstdio>
+
 #include <algorithm>
 #include <list>
 #include <mutex>
@@ -897,27 +900,46 @@ std::vector<int64_t> ZincProver::get_z_ccs(const ccs::Statement_Z &statement, co
 }
 
 namespace {
-struct CcsHandle {
-    zip_ccs *h = nullptr;
-    ~CcsHandle() { zip_ccs_free(h); }
-    void check(int32_t rc, const char *what) const {
-        if (rc == ZIP_OK) return;
-        const std::string msg = std::string(what) + ": " + (h ? zip_ccs_last_error(h) : zip_strerror(rc));
-        if (rc == ZIP_ERR_SHAPE) throw std::logic_error(msg);  // the reference panics / LengthsNotEqual
-        throw ZipError(rc == ZIP_ERR_INVALID_PARAM ? ZipError::InvalidPcsParam : ZipError::Device, msg);
-    }
-    const uint64_t *table(zip_ccs_table_kind which, uint32_t index) const {
-        const uint64_t *p = nullptr;
-        check(zip_ccs_table(h, which, index, &p), "zip_ccs_table");
-        return p;
+// ZINC_HOST_TIMING=1: stage times of the prover on stderr (tools/zinc_prover_times.py)
+struct StageTimer {
+    bool on = std::getenv("ZINC_HOST_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[zinc] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
     }
 };
+void ccs_check(zip_ccs *h, int32_t rc, const char *what) {
+    if (rc == ZIP_OK) return;
+    const std::string msg = std::string(what) + ": " + (h ? zip_ccs_last_error(h) : zip_strerror(rc));
+    if (rc == ZIP_ERR_SHAPE) throw std::logic_error(msg);  // the reference panics / LengthsNotEqual
+    throw ZipError(rc == ZIP_ERR_INVALID_PARAM ? ZipError::InvalidPcsParam : ZipError::Device, msg);
+}
+const uint64_t *ccs_table(zip_ccs *h, zip_ccs_table_kind which, uint32_t index) {
+    const uint64_t *p = nullptr;
+    ccs_check(h, zip_ccs_table(h, which, index, &p), "zip_ccs_table");
+    return p;
+}
 }  // namespace
+
+PreparedCcs::PreparedCcs(const ccs::Statement_Z &statement, const ccs::CCS_Z &ccs, const FieldConfig &config, int device)
+    : t_((uint32_t)ccs.t), s_((uint32_t)ccs.s), limbs_(config.limbs), modulus_(config.modulus), device_(device) {
+    if (ccs.s == 0 || ccs.s > 28 || ccs.m != ((size_t)1 << ccs.s) || ccs.n != ccs.m || ccs.s_prime != ccs.s)
+        throw std::logic_error("assertion failed: rx.len() == num_rows (compute_eval_table_sparse): m == n == 2^s is required");
+    if (statement.constraints.size() != ccs.t) throw std::logic_error("CCS sizes and the statement disagree");
+    const zip_field zf = config.to_abi();
+    std::vector<zip_sparse_matrix> mats;
+    for (const auto &M : statement.constraints) mats.push_back(M.to_abi());
+    ccs_check(nullptr, zip_ccs_create(device, mats.data(), t_, s_, &zf, &h_), "zip_ccs_create");
+}
+PreparedCcs::~PreparedCcs() { zip_ccs_free(h_); }
 
 std::pair<SpartanProof, std::vector<Limbs>> ZincProver::spartan_prove(const ccs::Statement_Z &statement,
                                                                       const std::vector<int64_t> &z_ccs,
                                                                       KeccakTranscript &transcript, const ccs::CCS_Z &ccs,
-                                                                      const FieldConfig &config) const {
+                                                                      const FieldConfig &config, PreparedCcs *prepared) const {
     // the shape the reference's prover supports (see the header)
     if (ccs.s == 0 || ccs.s > 28 || ccs.m != ((size_t)1 << ccs.s) || ccs.n != ccs.m || ccs.s_prime != ccs.s)
         throw std::logic_error("assertion failed: rx.len() == num_rows (compute_eval_table_sparse): m == n == 2^s is required");
@@ -936,14 +958,22 @@ std::pair<SpartanProof, std::vector<Limbs>> ZincProver::spartan_prove(const ccs:
         }
         if (pos != ccs.t) throw ZipError(ZipError::InvalidPcsParam, "ccs.S must list the matrices 0..t-1 in order");
     }
-    const zip_field zf = config.to_abi();
     const uint32_t s = (uint32_t)ccs.s, t = (uint32_t)ccs.t;
-    std::vector<zip_sparse_matrix> mats;
-    for (const auto &M : statement.constraints) mats.push_back(M.to_abi());
-    CcsHandle dev;
-    dev.check(zip_ccs_create(device_, mats.data(), t, s, &zf, &dev.h), "zip_ccs_create");
-    // prepare_for_random_field_piop: z_ccs -> F_q; calculate_Mz_mles
-    dev.check(zip_ccs_set_z(dev.h, z_ccs.data(), z_ccs.size(), ZIP_MEM_HOST), "zip_ccs_set_z");
+    StageTimer timer;
+    std::unique_ptr<PreparedCcs> own;
+    if (!prepared) {  // prepare_for_random_field_piop: ccs.map_to_field / statement.map_to_field
+        own = std::make_unique<PreparedCcs>(statement, ccs, config, device_);
+        prepared = own.get();
+        timer.lap("PreparedCcs (zip_ccs_create)");
+    } else if (prepared->t_ != t || prepared->s_ != s || prepared->limbs_ != config.limbs ||
+               prepared->modulus_ != config.modulus || prepared->device_ != device_) {
+        throw std::logic_error("the prepared CCS belongs to another circuit, field or device");
+    }
+    std::lock_guard<std::mutex> one_proof(prepared->mu_);
+    zip_ccs *dev = prepared->h_;
+    // z_ccs -> F_q (prover.rs:236); calculate_Mz_mles
+    ccs_check(dev, zip_ccs_set_z(dev, z_ccs.data(), z_ccs.size(), ZIP_MEM_HOST), "zip_ccs_set_z");
+    timer.lap("zip_ccs_set_z");
 
     SpartanProof proof;
     // ---- sumcheck_1 (prover.rs:242-259)
@@ -953,15 +983,16 @@ std::pair<SpartanProof, std::vector<Limbs>> ZincProver::spartan_prove(const ccs:
         const Limbs b = transcript.get_challenge(config);
         std::copy(b.begin(), b.begin() + config.limbs, flat.begin() + (size_t)i * config.limbs);
     }
-    dev.check(zip_ccs_eq_table(dev.h, flat.data(), 0), "zip_ccs_eq_table");
+    ccs_check(dev, zip_ccs_eq_table(dev, flat.data(), 0), "zip_ccs_eq_table");
     std::vector<const uint64_t *> g;  // prepare_lin_sumcheck_polynomial: [Mz_0 .. Mz_{t-1}, eq(beta)], degree d + 1
-    for (uint32_t k = 0; k < t; k++) g.push_back(dev.table(ZIP_CCS_MZ, k));
-    g.push_back(dev.table(ZIP_CCS_EQ, 0));
+    for (uint32_t k = 0; k < t; k++) g.push_back(ccs_table(dev, ZIP_CCS_MZ, k));
+    g.push_back(ccs_table(dev, ZIP_CCS_EQ, 0));
     std::vector<Limbs> c_f;
     for (int64_t c : ccs.c) c_f.push_back(map_to_field(config, c));  // CCS_Z::map_to_field, ccs_z.rs:147
     const zip_sumcheck_comb comb = make_comb(g.size(), c_f, S, config);
     auto sc1 = prove_as_subprotocol_impl(transcript, g, s, (uint32_t)ccs.d + 1, &comb, config, device_, ZIP_MEM_DEVICE);
     proof.linearization_sumcheck = std::move(sc1.proof);
+    timer.lap("sumcheck_1");
     const std::vector<Limbs> &r_x = sc1.randomness;
 
     // ---- sumcheck_2 (prover.rs:261-303)
@@ -969,10 +1000,12 @@ std::pair<SpartanProof, std::vector<Limbs>> ZincProver::spartan_prove(const ccs:
     const Limbs gamma = transcript.get_challenge(config);
     for (uint32_t i = 0; i < s; i++) std::copy(r_x[i].begin(), r_x[i].begin() + config.limbs, flat.begin() + (size_t)i * config.limbs);
     std::vector<uint64_t> vs((size_t)t * config.limbs);
-    dev.check(zip_ccs_second_table(dev.h, flat.data(), gamma.data(), vs.data()), "zip_ccs_second_table");
-    const std::vector<const uint64_t *> two{dev.table(ZIP_CCS_SECOND, 0), dev.table(ZIP_CCS_Z_FIELD, 0)};
+    ccs_check(dev, zip_ccs_second_table(dev, flat.data(), gamma.data(), vs.data()), "zip_ccs_second_table");
+    timer.lap("zip_ccs_second_table");
+    const std::vector<const uint64_t *> two{ccs_table(dev, ZIP_CCS_SECOND, 0), ccs_table(dev, ZIP_CCS_Z_FIELD, 0)};
     auto sc2 = prove_as_subprotocol_impl(transcript, two, s, 2, nullptr, config, device_, ZIP_MEM_DEVICE);
     proof.second_sumcheck = std::move(sc2.proof);
+    timer.lap("sumcheck_2");
 
     // ---- calculate_V_s (prover.rs:330-347), computed with the second table
     for (uint32_t k = 0; k < t; k++) {
@@ -984,16 +1017,20 @@ std::pair<SpartanProof, std::vector<Limbs>> ZincProver::spartan_prove(const ccs:
 }
 
 ZincProof ZincProver::prove(const ccs::Statement_Z &statement, const ccs::Witness_Z &wit, KeccakTranscript &transcript,
-                            const ccs::CCS_Z &ccs, const FieldConfig &config) const {
+                            const ccs::CCS_Z &ccs, const FieldConfig &config, std::vector<Limbs> *r_y_out,
+                            PreparedCcs *prepared) const {
     const std::vector<int64_t> z_ccs = get_z_ccs(statement, wit, ccs);
-    auto [spartan_proof, r_y] = spartan_prove(statement, z_ccs, transcript, ccs, config);
+    auto [spartan_proof, r_y] = spartan_prove(statement, z_ccs, transcript, ccs, config, prepared);
     // commit_z_mle_and_prove_evaluation (prover.rs:305-327); z_mle = from_evaluations_slice(s_prime, z_ccs)
     std::vector<int64_t> z_mle(z_ccs);
     z_mle.resize((size_t)1 << ccs.s_prime, 0);
     ZincProof out;
     out.spartan_proof = std::move(spartan_proof);
+    StageTimer timer;
     out.zip_proof = zip::commit_z_mle_and_prove_evaluation(lc_spec_, z_mle.data(), ccs.m, r_y.data(), r_y.size(), transcript,
                                                            config, device_);
+    timer.lap("commit_z_mle_and_prove_eval");
+    if (r_y_out) *r_y_out = std::move(r_y);
     return out;
 }
 

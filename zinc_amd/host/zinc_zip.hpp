@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <type_traits>
 #include <utility>
@@ -313,16 +314,39 @@ struct ZincProof {
 // reference's own code supports (compute_eval_table_sparse asserts rx.len() == ccs.n, ccs_f.rs:133;
 // sumcheck_polynomial_comb_fn_1 indexes the MLE list by matrix number, zinc/utils.rs:84-88);
 // anything else throws std::logic_error where the reference panics.
+// The constraint matrices of one circuit in HBM (F_q values in CSR and CSC order) with the proof-time tables
+// beside them.  What prepare_for_random_field_piop recomputes per proof in the reference
+// (ccs.map_to_field / statement.map_to_field, prover.rs:188-189) depends only on the circuit and the field:
+// build it once, hand it to every proof.  One proof at a time per object (internally locked).
+class PreparedCcs {
+  public:
+    PreparedCcs(const ccs::Statement_Z &statement, const ccs::CCS_Z &ccs, const FieldConfig &config, int device = 0);
+    ~PreparedCcs();
+    PreparedCcs(const PreparedCcs &) = delete;
+    PreparedCcs &operator=(const PreparedCcs &) = delete;
+
+  private:
+    friend class ZincProver;
+    zip_ccs *h_ = nullptr;
+    std::mutex mu_;
+    uint32_t t_ = 0, s_ = 0, limbs_ = 0;
+    Limbs modulus_{};
+    int device_ = 0;
+};
+
 class ZincProver {
   public:
     explicit ZincProver(zip::LinearCodeSpec spec = {}, int device = 0) : lc_spec_(spec), device_(device) {}
     // Prover::prove (prover.rs:50-88)
+    // r_y_out: the second sumcheck's point (the verifier re-derives it; handed out for tests and tools)
+    // prepared: the circuit's matrices already on the device (must come from the same statement and field)
     ZincProof prove(const ccs::Statement_Z &statement, const ccs::Witness_Z &wit, KeccakTranscript &transcript,
-                    const ccs::CCS_Z &ccs, const FieldConfig &config) const;
+                    const ccs::CCS_Z &ccs, const FieldConfig &config, std::vector<Limbs> *r_y_out = nullptr,
+                    PreparedCcs *prepared = nullptr) const;
     // prepare_for_random_field_piop (:172-191, the z vector) + SpartanProver::prove (:130-161)
     std::pair<SpartanProof, std::vector<Limbs>> spartan_prove(const ccs::Statement_Z &statement, const std::vector<int64_t> &z_ccs,
                                                               KeccakTranscript &transcript, const ccs::CCS_Z &ccs,
-                                                              const FieldConfig &config) const;
+                                                              const FieldConfig &config, PreparedCcs *prepared = nullptr) const;
     // get_z_ccs_and_z_mle (:222-239): x || 1 || w, zero-extended to ccs.m
     static std::vector<int64_t> get_z_ccs(const ccs::Statement_Z &statement, const ccs::Witness_Z &wit, const ccs::CCS_Z &ccs);
 

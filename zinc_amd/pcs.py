@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = (
     "zinc_pcs_transcript_probe", "zinc_zip_open", "zinc_pcs_transcript_from_proof", "zinc_pcs_transcript_position",
     "zinc_zip_verify", "zinc_zip_evaluate", "zinc_commit_z_mle_and_prove_evaluation", "zinc_zip_proof_len",
     "zinc_zip_proof_num_roots", "zinc_zip_proof_read", "zinc_zip_proof_free", "zinc_zip_release_cached_contexts", "zinc_sumcheck_prove_product", "zinc_sumcheck_prove_ccs", "zinc_zip_data_download", "zinc_zip_data_upload", "zinc_merkle_tree_new",
-    "zinc_prover_prove",
+    "zinc_prover_prove", "zinc_prover_prepare", "zinc_prepared_ccs_free",
 )
 
 
@@ -108,7 +108,11 @@ def lib():
         L.zinc_merkle_tree_new.argtypes = [C.c_uint32, vp, C.c_size_t, C.c_uint32, C.c_int32, vp]
         L.zinc_sumcheck_prove_product.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_int32, vp, vp]
         L.zinc_prover_prove.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_size_t, vp,
-                                        C.c_size_t, vp, vp, C.c_uint32, C.c_int32, C.c_int32, vp, vp, vp, vp, C.POINTER(vp)]
+                                        C.c_size_t, vp, vp, C.c_uint32, C.c_int32, vp, C.c_int32, vp, vp, vp, vp,
+                                        C.POINTER(vp)]
+        L.zinc_prover_prepare.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_int32, C.POINTER(vp)]
+        L.zinc_prepared_ccs_free.argtypes = [vp]
+        L.zinc_prepared_ccs_free.restype = None
         _lib = L
     return _lib
 
@@ -437,13 +441,25 @@ class ZincProver:
     def __init__(self, device: int = 0):
         self.device = device
 
-    def _run(self, matrices, s, d, S, c, public_input, w_ccs, transcript, field, with_pcs):
-        t, fl = len(matrices), field.limbs
+    @staticmethod
+    def _abi_matrices(matrices):
         keep = [(np.ascontiguousarray(M.row_ptr, dtype=np.uint32), np.ascontiguousarray(M.col_idx, dtype=np.uint32),
                  np.ascontiguousarray(M.values, dtype=np.int64)) for M in matrices]
-        arr = (cabi.SparseMatrix * t)()
+        arr = (cabi.SparseMatrix * len(matrices))()
         for k, (M, (rp, ci, va)) in enumerate(zip(matrices, keep)):
             arr[k] = cabi.SparseMatrix(M.n_rows, M.n_cols, rp.ctypes.data, ci.ctypes.data, va.ctypes.data)
+        return arr, keep
+
+    def prepare(self, matrices, s, field: "FieldConfig") -> "PreparedCcs":
+        """The circuit's matrices in F_q on the device, for every later proof of that circuit (PreparedCcs)."""
+        arr, _keep = self._abi_matrices(matrices)
+        h = C.c_void_p()
+        _check(lib().zinc_prover_prepare(arr, len(matrices), s, field._m.ctypes.data, field.limbs, self.device, C.byref(h)))
+        return PreparedCcs(h)
+
+    def _run(self, matrices, s, d, S, c, public_input, w_ccs, transcript, field, with_pcs, prepared=None):
+        t, fl = len(matrices), field.limbs
+        arr, _keep = self._abi_matrices(matrices)
         masks = np.array([sum(1 << j for j in Si) for Si in S], dtype=np.uint32)
         cv = np.array(c, dtype=np.int64)
         x = np.ascontiguousarray(public_input, dtype=np.int64)
@@ -453,7 +469,7 @@ class ZincProver:
         h = C.c_void_p()
         _check(lib().zinc_prover_prove(arr, t, s, d, len(S), masks.ctypes.data, cv.ctypes.data, x.ctypes.data, x.size,
                                        w.ctypes.data, w.size, transcript._h, field._m.ctypes.data, fl, self.device,
-                                       1 if with_pcs else 0, out["msgs1"].ctypes.data, out["msgs2"].ctypes.data,
+                                       prepared._h if prepared is not None else None, 1 if with_pcs else 0, out["msgs1"].ctypes.data, out["msgs2"].ctypes.data,
                                        out["V_s"].ctypes.data, out["r_y"].ctypes.data, C.byref(h)))
         if with_pcs:
             try:
@@ -466,10 +482,22 @@ class ZincProver:
             out["zip_proof"] = dict(z_comm=roots, v=v, pcs_proof=proof)
         return out
 
-    def spartan_prove(self, matrices, s, d, S, c, public_input, w_ccs, transcript: KeccakTranscript, field: FieldConfig):
+    def spartan_prove(self, matrices, s, d, S, c, public_input, w_ccs, transcript: KeccakTranscript, field: FieldConfig,
+                      prepared=None):
         """prepare_for_random_field_piop + SpartanProver::prove (prover.rs:130-161) -> SpartanProof fields + r_y."""
-        return self._run(matrices, s, d, S, c, public_input, w_ccs, transcript, field, False)
+        return self._run(matrices, s, d, S, c, public_input, w_ccs, transcript, field, False, prepared)
 
-    def prove(self, matrices, s, d, S, c, public_input, w_ccs, transcript: KeccakTranscript, field: FieldConfig):
+    def prove(self, matrices, s, d, S, c, public_input, w_ccs, transcript: KeccakTranscript, field: FieldConfig,
+              prepared=None):
         """Prover::prove (prover.rs:50-88) -> ZincProof {spartan_proof, zip_proof}."""
-        return self._run(matrices, s, d, S, c, public_input, w_ccs, transcript, field, True)
+        return self._run(matrices, s, d, S, c, public_input, w_ccs, transcript, field, True, prepared)
+
+
+class PreparedCcs:
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().zinc_prepared_ccs_free(self._h)
+            self._h = None
