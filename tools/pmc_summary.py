@@ -37,7 +37,7 @@ def pmc(d, counter):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trace"), ap.add_argument("--fetch"), ap.add_argument("--write")
-    ap.add_argument("--sq"), ap.add_argument("--verify"), ap.add_argument("--sumcheck")
+    ap.add_argument("--sq"), ap.add_argument("--verify"), ap.add_argument("--sumcheck"), ap.add_argument("--prover")
     ap.add_argument("--tag", default="round1")
     ap.add_argument("--num-vars", type=int, default=24)
     a = ap.parse_args()
@@ -47,7 +47,7 @@ def main():
         st = find(a.trace, "*kernel_stats.csv")
         if st:
             shutil.copy(st, os.path.join(prof, f"{a.tag}_kernel_stats.csv"))
-    for d, name in ((a.verify, "verify"), (a.sumcheck, "sumcheck")):
+    for d, name in ((a.verify, "verify"), (a.sumcheck, "sumcheck"), (a.prover, "prover")):
         st = find(d, "*kernel_stats.csv") if d else None
         if st:
             shutil.copy(st, os.path.join(prof, f"{a.tag}_{name}_kernel_stats.csv"))

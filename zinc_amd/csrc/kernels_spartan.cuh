@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(256) field_map_i64_kernel(const int64_t *in, u
 // eq(x, r)[i] = prod_j (bit_j(i) ? r_j : 1 - r_j), variable 0 = least significant bit of i.
 // r: nv Montgomery elements in HBM.  The reference builds the table by doubling; products of exact
 // residues do not depend on the order.
+// (large tables are built from two small ones, see eq_outer_kernel)
 template <int FL>
 __global__ void __launch_bounds__(256) eq_table_kernel(const uint64_t *r, uint32_t nv, uint64_t *out, FieldDev<FL> f) {
     __shared__ uint64_t fac[2][32][FL];  // [bit][j]
@@ -96,6 +97,20 @@ __global__ void __launch_bounds__(256) eq_table_kernel(const uint64_t *r, uint32
             for (int k = 0; k < FL; k++) acc[k] = t[k];
         }
         fe_store<FL>(out + i * FL, acc);
+    }
+}
+
+// eq over nv variables as the outer product of the tables over the low nv_lo and the remaining high
+// variables: out[i] = lo[i mod 2^nv_lo] (x) hi[i >> nv_lo] -- one multiplication per entry instead of nv - 1.
+template <int FL>
+__global__ void __launch_bounds__(256) eq_outer_kernel(const uint64_t *lo, const uint64_t *hi, uint32_t nv_lo, uint64_t n,
+                                                       uint64_t *out, FieldDev<FL> f) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t a[FL], b[FL], t[FL];
+        fe_load<FL>(a, lo + (i & (((uint64_t)1 << nv_lo) - 1)) * FL);
+        fe_load<FL>(b, hi + (i >> nv_lo) * FL);
+        mont_mul<FL>(a, b, f, t);
+        fe_store<FL>(out + i * FL, t);
     }
 }
 

@@ -131,6 +131,7 @@ struct zip_ccs {
     } mat[kCcsMaxMatrices];
     uint64_t *z_f = nullptr, *mz[kCcsMaxMatrices] = {}, *eq[2] = {}, *second = nullptr;
     uint64_t *small_d = nullptr, *partials = nullptr;  // challenges in; dot-product partials
+    uint64_t *eq_half = nullptr;                       // eq tables over the low / high half of the variables
     uint32_t dot_blocks = 0;
     bool have_z = false, have_eq[2] = {false, false}, have_second = false;
 };
@@ -1101,9 +1102,24 @@ int32_t ccs_set_z_fl(zip_ccs *c, const int64_t *z_d, size_t z_len, const HostFie
 template <int FL>
 int32_t ccs_eq_table_fl(zip_ccs *c, const uint64_t *r_d, uint32_t slot, const HostField &hf) {
     zip_ctx *ctx = c->ctx;
+    const FieldDev<FL> fd = to_dev<FL>(hf);
+    auto direct = [&](const uint64_t *r, uint32_t nv, uint64_t *out) -> int32_t {
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((((uint64_t)1 << nv) + 255) / 256, 65535);
+        LaunchTimer t(ctx, "eq_table_kernel");
+        hipLaunchKernelGGL(eq_table_kernel<FL>, dim3(blocks), dim3(256), 0, ctx->stream, r, nv, out, fd);
+        HIP_TRY(ctx, hipGetLastError());
+        return ZIP_OK;
+    };
+    if (c->s < 12) return direct(r_d, c->s, c->eq[slot]);
+    // eq(x, r) = eq(x_lo, r_lo) * eq(x_hi, r_hi): two small tables, then one multiplication per entry
+    const uint32_t nv_lo = c->s / 2, nv_hi = c->s - nv_lo;
+    uint64_t *lo = c->eq_half, *hi = c->eq_half + ((size_t)FL << nv_lo);
+    int32_t rc;
+    if ((rc = direct(r_d, nv_lo, lo))) return rc;
+    if ((rc = direct(r_d + (size_t)nv_lo * FL, nv_hi, hi))) return rc;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)c->m + 255) / 256, 65535);
-    LaunchTimer t(ctx, "eq_table_kernel");
-    hipLaunchKernelGGL(eq_table_kernel<FL>, dim3(blocks), dim3(256), 0, ctx->stream, r_d, c->s, c->eq[slot], to_dev<FL>(hf));
+    LaunchTimer t(ctx, "eq_outer_kernel");
+    hipLaunchKernelGGL(eq_outer_kernel<FL>, dim3(blocks), dim3(256), 0, ctx->stream, lo, hi, nv_lo, (uint64_t)c->m, c->eq[slot], fd);
     HIP_TRY(ctx, hipGetLastError());
     return ZIP_OK;
 }
@@ -2200,6 +2216,7 @@ int32_t zip_ccs_create(int32_t device, const zip_sparse_matrix *mats, uint32_t t
         if ((rc = pool_alloc(ctx, tab, (void **)&c->eq[1]))) break;
         if ((rc = pool_alloc(ctx, tab, (void **)&c->second))) break;
         if ((rc = pool_alloc(ctx, (size_t)(40 + kCcsMaxMatrices) * 64, (void **)&c->small_d))) break;
+        if ((rc = pool_alloc(ctx, (((size_t)1 << (s / 2)) + ((size_t)1 << (s - s / 2))) * elem, (void **)&c->eq_half))) break;
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
         c->dot_blocks = (uint32_t)std::min<uint64_t>(((uint64_t)m + 255) / 256, (uint64_t)cus * 4);
