@@ -388,17 +388,16 @@ int32_t zinc_prover_prove(const zip_sparse_matrix *constraints, uint32_t t, uint
         else st = statement_from_abi(constraints, t);
         st.public_input.assign(public_input, public_input + l);
         zinc::PreparedCcs *prep = prepared ? prepared->p.get() : nullptr;
-        zinc::ccs::Witness_Z wit;
-        wit.w_ccs.assign(w_ccs, w_ccs + w_len);
+        const zinc::IntVec z = zinc::ZincProver::get_z_ccs(public_input, l, w_ccs, w_len, ccs.m);  // x || 1 || w
         const zinc::ZincProver prover(LinearCodeSpec{}, device);
         zinc::SpartanProof sp;
         std::vector<Limbs> r_y;
         if (with_pcs) {
-            auto proof = prover.prove(st, wit, transcript->t, ccs, f, &r_y, prep);
+            auto proof = prover.prove_z(st, z.data(), z.size(), transcript->t, ccs, f, &r_y, prep);
             sp = std::move(proof.spartan_proof);
             *zip_proof_out = new zinc_zip_proof{std::move(proof.zip_proof), limbs};
         } else {
-            auto res = prover.spartan_prove(st, zinc::ZincProver::get_z_ccs(st, wit, ccs), transcript->t, ccs, f, prep);
+            auto res = prover.spartan_prove(st, z.data(), z.size(), transcript->t, ccs, f, prep);
             sp = std::move(res.first);
             r_y = std::move(res.second);
         }

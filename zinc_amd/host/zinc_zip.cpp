@@ -892,10 +892,13 @@ std::vector<int64_t> ccs::Statement_Z::get_z_vector(const std::vector<int64_t> &
 }
 
 // ---------------------------------------------------------------------------- ZincProver
-std::vector<int64_t> ZincProver::get_z_ccs(const ccs::Statement_Z &statement, const ccs::Witness_Z &wit,
-                                           const ccs::CCS_Z &ccs) {
-    std::vector<int64_t> z = statement.get_z_vector(wit.w_ccs);
-    if (z.size() <= ccs.m) z.resize(ccs.m, 0);  // prover.rs:230-232
+IntVec ZincProver::get_z_ccs(const int64_t *x, size_t l, const int64_t *w, size_t w_len, size_t m) {
+    const size_t len = l + 1 + w_len;
+    IntVec z(len <= m ? m : len);  // prover.rs:230-232: resize(ccs.m) only when not longer
+    if (l) std::memcpy(z.data(), x, l * 8);
+    z[l] = 1;
+    if (w_len) std::memcpy(z.data() + l + 1, w, w_len * 8);
+    if (z.size() > len) std::memset(z.data() + len, 0, (z.size() - len) * 8);
     return z;
 }
 
@@ -937,7 +940,7 @@ PreparedCcs::PreparedCcs(const ccs::Statement_Z &statement, const ccs::CCS_Z &cc
 PreparedCcs::~PreparedCcs() { zip_ccs_free(h_); }
 
 std::pair<SpartanProof, std::vector<Limbs>> ZincProver::spartan_prove(const ccs::Statement_Z &statement,
-                                                                      const std::vector<int64_t> &z_ccs,
+                                                                      const int64_t *z_ccs, size_t z_len,
                                                                       KeccakTranscript &transcript, const ccs::CCS_Z &ccs,
                                                                       const FieldConfig &config, PreparedCcs *prepared) const {
     // the shape the reference's prover supports (see the header)
@@ -945,7 +948,7 @@ std::pair<SpartanProof, std::vector<Limbs>> ZincProver::spartan_prove(const ccs:
         throw std::logic_error("assertion failed: rx.len() == num_rows (compute_eval_table_sparse): m == n == 2^s is required");
     if (statement.constraints.size() != ccs.t || ccs.S.size() != ccs.q || ccs.c.size() != ccs.q)
         throw std::logic_error("CCS sizes and the statement disagree");
-    if (z_ccs.size() > ccs.m) throw std::logic_error("LengthsNotEqual: M.n_cols != z.len()");
+    if (z_len > ccs.m) throw std::logic_error("LengthsNotEqual: M.n_cols != z.len()");
     std::vector<std::vector<uint32_t>> S(ccs.q);
     {
         size_t pos = 0;
@@ -972,7 +975,7 @@ std::pair<SpartanProof, std::vector<Limbs>> ZincProver::spartan_prove(const ccs:
     std::lock_guard<std::mutex> one_proof(prepared->mu_);
     zip_ccs *dev = prepared->h_;
     // z_ccs -> F_q (prover.rs:236); calculate_Mz_mles
-    ccs_check(dev, zip_ccs_set_z(dev, z_ccs.data(), z_ccs.size(), ZIP_MEM_HOST), "zip_ccs_set_z");
+    ccs_check(dev, zip_ccs_set_z(dev, z_ccs, z_len, ZIP_MEM_HOST), "zip_ccs_set_z");
     timer.lap("zip_ccs_set_z");
 
     SpartanProof proof;
@@ -1019,15 +1022,28 @@ std::pair<SpartanProof, std::vector<Limbs>> ZincProver::spartan_prove(const ccs:
 ZincProof ZincProver::prove(const ccs::Statement_Z &statement, const ccs::Witness_Z &wit, KeccakTranscript &transcript,
                             const ccs::CCS_Z &ccs, const FieldConfig &config, std::vector<Limbs> *r_y_out,
                             PreparedCcs *prepared) const {
-    const std::vector<int64_t> z_ccs = get_z_ccs(statement, wit, ccs);
-    auto [spartan_proof, r_y] = spartan_prove(statement, z_ccs, transcript, ccs, config, prepared);
+    const IntVec z_ccs = get_z_ccs(statement, wit, ccs);
+    return prove_z(statement, z_ccs.data(), z_ccs.size(), transcript, ccs, config, r_y_out, prepared);
+}
+
+ZincProof ZincProver::prove_z(const ccs::Statement_Z &statement, const int64_t *z_ccs, size_t z_len, KeccakTranscript &transcript,
+                              const ccs::CCS_Z &ccs, const FieldConfig &config, std::vector<Limbs> *r_y_out,
+                              PreparedCcs *prepared) const {
+    auto [spartan_proof, r_y] = spartan_prove(statement, z_ccs, z_len, transcript, ccs, config, prepared);
     // commit_z_mle_and_prove_evaluation (prover.rs:305-327); z_mle = from_evaluations_slice(s_prime, z_ccs)
-    std::vector<int64_t> z_mle(z_ccs);
-    z_mle.resize((size_t)1 << ccs.s_prime, 0);
+    const size_t n_mle = (size_t)1 << ccs.s_prime;
+    IntVec padded;
+    const int64_t *z_mle = z_ccs;
+    if (z_len != n_mle) {
+        padded.resize(n_mle);
+        std::memcpy(padded.data(), z_ccs, std::min(z_len, n_mle) * 8);
+        if (z_len < n_mle) std::memset(padded.data() + z_len, 0, (n_mle - z_len) * 8);
+        z_mle = padded.data();
+    }
     ZincProof out;
     out.spartan_proof = std::move(spartan_proof);
     StageTimer timer;
-    out.zip_proof = zip::commit_z_mle_and_prove_evaluation(lc_spec_, z_mle.data(), ccs.m, r_y.data(), r_y.size(), transcript,
+    out.zip_proof = zip::commit_z_mle_and_prove_evaluation(lc_spec_, z_mle, ccs.m, r_y.data(), r_y.size(), transcript,
                                                            config, device_);
     timer.lap("commit_z_mle_and_prove_eval");
     if (r_y_out) *r_y_out = std::move(r_y);

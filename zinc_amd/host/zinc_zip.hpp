@@ -58,6 +58,7 @@ void *byte_stream_alloc(size_t bytes);
 template <class T>
 void *default_init_allocator<T>::big_alloc(size_t bytes) { return byte_stream_alloc(bytes); }
 using ByteStream = std::vector<uint8_t, default_init_allocator<uint8_t>>;
+using IntVec = std::vector<int64_t, default_init_allocator<int64_t>>;  // witness-sized: huge pages, no zero fill
 
 constexpr uint32_t kMaxLimbs = 8;
 using Limbs = std::array<uint64_t, kMaxLimbs>;  // little-endian, unused limbs zero
@@ -343,12 +344,19 @@ class ZincProver {
     ZincProof prove(const ccs::Statement_Z &statement, const ccs::Witness_Z &wit, KeccakTranscript &transcript,
                     const ccs::CCS_Z &ccs, const FieldConfig &config, std::vector<Limbs> *r_y_out = nullptr,
                     PreparedCcs *prepared = nullptr) const;
+    // the same from the z vector itself (x || 1 || w, at most ccs.m entries; shorter vectors are zero-extended)
+    ZincProof prove_z(const ccs::Statement_Z &statement, const int64_t *z_ccs, size_t z_len, KeccakTranscript &transcript,
+                      const ccs::CCS_Z &ccs, const FieldConfig &config, std::vector<Limbs> *r_y_out = nullptr,
+                      PreparedCcs *prepared = nullptr) const;
     // prepare_for_random_field_piop (:172-191, the z vector) + SpartanProver::prove (:130-161)
-    std::pair<SpartanProof, std::vector<Limbs>> spartan_prove(const ccs::Statement_Z &statement, const std::vector<int64_t> &z_ccs,
+    std::pair<SpartanProof, std::vector<Limbs>> spartan_prove(const ccs::Statement_Z &statement, const int64_t *z_ccs, size_t z_len,
                                                               KeccakTranscript &transcript, const ccs::CCS_Z &ccs,
                                                               const FieldConfig &config, PreparedCcs *prepared = nullptr) const;
     // get_z_ccs_and_z_mle (:222-239): x || 1 || w, zero-extended to ccs.m
-    static std::vector<int64_t> get_z_ccs(const ccs::Statement_Z &statement, const ccs::Witness_Z &wit, const ccs::CCS_Z &ccs);
+    static IntVec get_z_ccs(const int64_t *x, size_t l, const int64_t *w, size_t w_len, size_t m);
+    static IntVec get_z_ccs(const ccs::Statement_Z &statement, const ccs::Witness_Z &wit, const ccs::CCS_Z &ccs) {
+        return get_z_ccs(statement.public_input.data(), statement.public_input.size(), wit.w_ccs.data(), wit.w_ccs.size(), ccs.m);
+    }
 
   private:
     zip::LinearCodeSpec lc_spec_;
