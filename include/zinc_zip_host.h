@@ -159,6 +159,20 @@ int32_t zinc_prover_prove(const zip_sparse_matrix *constraints, uint32_t t, uint
                           uint64_t *msgs1_out, uint64_t *msgs2_out, uint64_t *v_s_out, uint64_t *r_y_out,
                           zinc_zip_proof **zip_proof_out);
 
+/* ZincVerifier (src/zinc/verifier.rs): SpartanVerifier::verify (:105-139), and with with_pcs != 0 also
+ * verify_pcs_proof (:221-273: RaaCode::new from the transcript, MultilinearZip::verify, the matrix MLEs at
+ * (r_x, r_y) on the device, the final equation) -- Verifier::verify without its draw_random_field check.
+ * Proof fields as zinc_prover_prove returns them.  rx_ry_out: 2 s elements; e_y_out, gamma_out: one element (any
+ * may be NULL).  ZINC_ERR_SPARTAN: a sumcheck or the final equation failed; ZINC_ERR_INVALID_OPEN: the Zip
+ * verifier rejected; zinc_last_error() has the message. */
+#define ZINC_ERR_SPARTAN (-6)
+int32_t zinc_verifier_verify(const zip_sparse_matrix *constraints, uint32_t t, uint32_t s, uint32_t d, uint32_t q,
+                             const uint32_t *s_masks, const int64_t *c, zinc_transcript *transcript, const uint64_t *modulus,
+                             uint32_t limbs, int32_t device, zinc_prepared_ccs *prepared, const uint64_t *msgs1,
+                             const uint64_t *msgs2, const uint64_t *v_s, int32_t with_pcs, const uint8_t *roots,
+                             size_t n_roots, const uint64_t *v, const uint8_t *pcs_proof, size_t pcs_proof_len,
+                             uint64_t *rx_ry_out, uint64_t *e_y_out, uint64_t *gamma_out);
+
 #ifdef __cplusplus
 }
 #endif

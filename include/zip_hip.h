@@ -251,6 +251,9 @@ void zip_sumcheck_free(zip_sumcheck *s);
  *   zip_ccs_second_table  what sumcheck_2 needs (prover.rs:261-296): eq(r_x) into slot 1, the table
  *                       sum_k gamma^k * compute_eval_table_sparse(M_k, eq(r_x)) (src/sparse_matrix.rs:165-182),
  *                       and V_s[k] = (M_k z)(r_x) (calculate_V_s, prover.rs:330-347) to v_s_out (HOST, t elements)
+ *   zip_ccs_eval_matrices  the verifier's V_xy (src/zinc/verifier.rs:248-261): mle[M_k](r_x, r_y) for every matrix,
+ *                       DenseMultilinearExtension::from_matrix (src/poly_f/mle/dense.rs:69-87) evaluated without
+ *                       building the dense 2^(2s) table; r_x, r_y: s elements each on the HOST; overwrites both eq slots
  *   zip_ccs_table       device pointer of a table of 2^s elements, valid until the next call that
  *                       rebuilds it or zip_ccs_free; index = matrix for ZIP_CCS_MZ, slot for ZIP_CCS_EQ
  *   zip_ccs_download    the same table copied to the HOST (tests) */
@@ -268,6 +271,7 @@ const char *zip_ccs_last_error(const zip_ccs *c);
 int32_t zip_ccs_set_z(zip_ccs *c, const int64_t *z, size_t z_len, zip_mem_kind kind);
 int32_t zip_ccs_eq_table(zip_ccs *c, const uint64_t *r, uint32_t slot);
 int32_t zip_ccs_second_table(zip_ccs *c, const uint64_t *r_x, const uint64_t *gamma, uint64_t *v_s_out);
+int32_t zip_ccs_eval_matrices(zip_ccs *c, const uint64_t *r_x, const uint64_t *r_y, uint64_t *v_xy_out);
 int32_t zip_ccs_table(zip_ccs *c, zip_ccs_table_kind which, uint32_t index, const uint64_t **table_dev);
 int32_t zip_ccs_download(zip_ccs *c, zip_ccs_table_kind which, uint32_t index, uint64_t *out);
 

@@ -1593,13 +1593,12 @@ int orc_spartan_verify(const orc_field *f, const orc_ccs *ccs, const uint64_t *m
  *   lin_comb(gamma, [mle(M_k)(r_x, r_y)]_k) * v == e_y,
  * with DenseMultilinearExtension::from_matrix (src/poly_f/mle/dense.rs:69-87: index = rows * col + row, so the
  * low s variables select the row) evaluated as sum val * eq(r_x)[row] * eq(r_y)[col]. */
-int orc_spartan_final_check(const orc_field *f, const orc_ccs *ccs, const uint64_t *r_x, const uint64_t *r_y,
-                            const uint64_t *gamma, const uint64_t *v, const uint64_t *e_y) {
+int orc_ccs_eval_matrices(const orc_field *f, const orc_ccs *ccs, const uint64_t *r_x, const uint64_t *r_y,
+                          uint64_t *v_xy) {
     int rc = ccs_check(ccs);
     if (rc) return rc;
     const uint32_t fl = f->fl, m = ccs->m;
     uint64_t *ex = calloc((size_t)m * fl, 8), *ey = calloc((size_t)m * fl, 8);
-    uint64_t vxy[8][ORC_MAX_FL];
     if (!ex || !ey) { free(ex); free(ey); return ORC_ERR_ALLOC; }
     orc_build_eq_x_r(f, r_x, ccs->s, ex);
     orc_build_eq_x_r(f, r_y, ccs->s_prime, ey);
@@ -1614,14 +1613,18 @@ int orc_spartan_final_check(const orc_field *f, const orc_ccs *ccs, const uint64
                 orc_field_mul(f, p, ey + (size_t)M->col_idx[e] * fl);
                 orc_field_add(f, acc, p);
             }
-        memcpy(vxy[k], acc, 8 * fl);
+        memcpy(v_xy + (size_t)k * fl, acc, 8 * fl);
     }
     free(ex); free(ey);
-    uint64_t lhs[ORC_MAX_FL] = {0}; /* lin_comb_V_s over V_xy */
-    for (int32_t i = (int32_t)ccs->t - 1; i >= 0; i--) {
-        orc_field_mul(f, lhs, gamma);
-        orc_field_add(f, lhs, vxy[i]);
-    }
+    return ORC_OK;
+}
+
+int orc_spartan_final_check(const orc_field *f, const orc_ccs *ccs, const uint64_t *r_x, const uint64_t *r_y,
+                            const uint64_t *gamma, const uint64_t *v, const uint64_t *e_y) {
+    uint64_t vxy[8 * ORC_MAX_FL], lhs[ORC_MAX_FL];
+    int rc = orc_ccs_eval_matrices(f, ccs, r_x, r_y, vxy);
+    if (rc) return rc;
+    lin_comb(f, gamma, vxy, ccs->t, lhs); /* lin_comb_V_s over V_xy */
     orc_field_mul(f, lhs, v);
-    return memcmp(lhs, e_y, 8 * fl) ? ORC_ERR_PROOF : ORC_OK;
+    return memcmp(lhs, e_y, 8 * f->fl) ? ORC_ERR_PROOF : ORC_OK;
 }

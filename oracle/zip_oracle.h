@@ -232,6 +232,9 @@ int orc_spartan_prove(const orc_field *f, const orc_ccs *ccs, const int64_t *z, 
 int orc_spartan_verify(const orc_field *f, const orc_ccs *ccs, const uint64_t *msgs1, const uint64_t *msgs2,
                        const uint64_t *V_s, orc_keccak *tr, uint64_t *r_x, uint64_t *r_y, uint64_t *e_y,
                        uint64_t *gamma);
+/* mle[M_k](r_x, r_y), k < t (DenseMultilinearExtension::from_matrix + evaluate, verifier.rs:248-261) */
+int orc_ccs_eval_matrices(const orc_field *f, const orc_ccs *ccs, const uint64_t *r_x, const uint64_t *r_y,
+                          uint64_t *v_xy);
 int orc_spartan_final_check(const orc_field *f, const orc_ccs *ccs, const uint64_t *r_x, const uint64_t *r_y,
                             const uint64_t *gamma, const uint64_t *v, const uint64_t *e_y);
 

@@ -272,6 +272,13 @@ class Ccs:
                                       _u64p(pts["gamma"]))
         return rc, pts
 
+    def eval_matrices(self, f: Field, r_x, r_y) -> np.ndarray:
+        out = np.zeros((self.inst.t, f.fl), dtype=np.uint64)
+        rc = lib().orc_ccs_eval_matrices(C.byref(f), C.byref(self.struct), _u64p(np.ascontiguousarray(r_x)),
+                                         _u64p(np.ascontiguousarray(r_y)), _u64p(out))
+        assert rc == 0, rc
+        return out
+
     def final_check(self, f: Field, pts, v: np.ndarray) -> int:
         return lib().orc_spartan_final_check(C.byref(f), C.byref(self.struct), _u64p(pts["r_x"]), _u64p(pts["r_y"]),
                                              _u64p(pts["gamma"]), _u64p(np.ascontiguousarray(v)), _u64p(pts["e_y"]))

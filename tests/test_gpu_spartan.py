@@ -208,3 +208,124 @@ def test_ccs_tables_at_2_pow_20(mods):
             assert np.array_equal(d.download(cabi.CCS_MZ, k), want[k]), (rep, k)
         d.free()
     cabi.lib().zip_release_cached_memory()
+
+
+# ------------------------------------------------------------------------------------------------ verifier
+@pytest.mark.parametrize("q,fl", FIELDS)
+@pytest.mark.parametrize("name,inst", _instances())
+def test_matrix_mles_at_a_point_equal_the_oracle(mods, q, fl, name, inst):
+    """V_xy of verify_pcs_proof (verifier.rs:248-261): mle[M_k](r_x, r_y) without the dense 2^(2s) table."""
+    cabi, _ = mods
+    f = orc.make_field(q, fl)
+    rng = np.random.default_rng(inst.s + 40)
+    rx = orc.field_elems([orc.field_from_i64(f, int(v)) for v in rng.integers(-2**62, 2**62, size=inst.s)], fl)
+    ry = orc.field_elems([orc.field_from_i64(f, int(v)) for v in rng.integers(-2**62, 2**62, size=inst.s)], fl)
+    d = cabi.Ccs(inst.matrices, inst.s, cabi.make_field(q, fl))
+    assert np.array_equal(d.eval_matrices(rx, ry), orc.Ccs(inst).eval_matrices(f, rx, ry))
+    d.free()
+
+
+def _args(inst):
+    return inst.matrices, inst.s, inst.d, inst.S, inst.c
+
+
+@pytest.mark.parametrize("q,fl", FIELDS)
+@pytest.mark.parametrize("name,inst", _instances())
+def test_spartan_verifier_mirror_equals_the_oracle(mods, q, fl, name, inst):
+    """SpartanVerifier::verify in the host mirror: same verification points as the oracle on honest proofs, same
+    rejections on tampered ones."""
+    _, pcs = mods
+    f = orc.make_field(q, fl)
+    field = pcs.FieldConfig(q, fl)
+    o = orc.Ccs(inst)
+    proof, _ = _device_spartan(pcs, inst, q, fl)
+    rc, want = o.spartan_verify(f, proof, orc.new_transcript())
+    assert rc == 0
+    got = pcs.ZincVerifier().spartan_verify(*_args(inst), proof, pcs.KeccakTranscript(), field)
+    assert np.array_equal(got["rx_ry"], np.concatenate([want["r_x"], want["r_y"]]))
+    assert np.array_equal(got["e_y"], want["e_y"]) and np.array_equal(got["gamma"], want["gamma"])
+    for key, idx in (("msgs1", (0, 1, 0)), ("msgs1", (inst.s - 1, 3, 0)), ("msgs2", (0, 0, 0)), ("V_s", (1, 0))):
+        bad = {k: v.copy() for k, v in proof.items()}
+        bad[key][idx] ^= np.uint64(2)
+        assert o.spartan_verify(f, bad, orc.new_transcript())[0] == orc.ORC_ERR_PROOF
+        with pytest.raises(pcs.SpartanError):
+            pcs.ZincVerifier().spartan_verify(*_args(inst), bad, pcs.KeccakTranscript(), field)
+    # the last round of the second sumcheck only moves e_y, which SpartanVerifier::verify hands on unchecked (the
+    # final equation of verify_pcs_proof catches it): accepted here by the reference, the oracle and the mirror
+    bad = {k: v.copy() for k, v in proof.items()}
+    bad["msgs2"][inst.s - 1, 2, 0] ^= np.uint64(2)
+    rc, moved = o.spartan_verify(f, bad, orc.new_transcript())
+    got = pcs.ZincVerifier().spartan_verify(*_args(inst), bad, pcs.KeccakTranscript(), field)
+    assert rc == 0 and np.array_equal(got["e_y"], moved["e_y"]) and not np.array_equal(moved["e_y"], want["e_y"])
+
+
+def test_failing_spartan_verifier_mirror(mods):
+    """zinc/tests.rs:159-209 with the mirror's verifier."""
+    _, pcs = mods
+    bad = _ccs.vitalik_ccs(3, break_witness=True)
+    proof, _ = _device_spartan(pcs, bad, Q192, 3)
+    with pytest.raises(pcs.SpartanError):
+        pcs.ZincVerifier().spartan_verify(*_args(bad), proof, pcs.KeccakTranscript(), pcs.FieldConfig(Q192, 3))
+
+
+@pytest.mark.parametrize("q,fl,log_n", [(Q192, 3, 4), (QSTARK, 4, 10), (Q128, 2, 6), (Q256, 4, 8)])
+def test_zinc_prove_then_verify_on_the_device(mods, q, fl, log_n):
+    """Prover::prove then Verifier::verify (without its field draw), both through the mirror; the verdicts and the
+    transcript state afterwards are the oracle's."""
+    _, pcs = mods
+    inst = _ccs.dummy_ccs_from_len(1 << log_n, seed=log_n + 1)
+    field = pcs.FieldConfig(q, fl)
+    proof, _ = _device_spartan(pcs, inst, q, fl, label=b"zv", with_pcs=True)
+    # the oracle's verifier over the same proof, for the expected verdict and the final transcript state
+    f = orc.make_field(q, fl)
+    o = orc.Ccs(inst)
+    kv = orc.new_transcript()
+    orc.absorb(kv, b"zv")
+    rc, pts = o.spartan_verify(f, proof, kv)
+    assert rc == 0
+    s1 = orc.lib().orc_tr_get_u64(orc.C.byref(kv))
+    s2 = orc.lib().orc_tr_get_u64(orc.C.byref(kv))
+    zp = proof["zip_proof"]
+    pcs_rc = orc.Zip(log_n, seeds=(s1, s2)).verify(f, zp["z_comm"], pts["r_y"], orc.limbs_to_int(zp["v"]), zp["pcs_proof"])
+
+    vt = pcs.KeccakTranscript()
+    vt.absorb(b"zv")
+    verifier = pcs.ZincVerifier()
+    if pcs_rc != 0:  # the modulus with the top bit set: the reference rejects its own PCS proofs
+        assert q == Q256
+        with pytest.raises(pcs.InvalidPcsOpen):
+            verifier.verify(*_args(inst), proof, vt, field)
+        return
+    got = verifier.verify(*_args(inst), proof, vt, field)
+    assert np.array_equal(got["rx_ry"][inst.s:], pts["r_y"])
+    assert vt.get_u64() == orc.lib().orc_tr_get_u64(orc.C.byref(kv))  # same Fiat-Shamir state after verification
+
+    def fresh():
+        t = pcs.KeccakTranscript()
+        t.absorb(b"zv")
+        return t
+
+    # a different circuit (C = diag(z) with one entry changed): both sumchecks and the PCS still pass, the final
+    # equation lin_comb(gamma, V_xy) * v == e_y (verifier.rs:264-269) does not
+    other = _ccs.dummy_ccs(inst.z.copy())
+    other.matrices[2].values = other.matrices[2].values.copy()
+    other.matrices[2].values[3] += 1
+    with pytest.raises(pcs.SpartanError, match="e_y"):
+        verifier.verify(*_args(other), proof, fresh(), field)
+    assert o.final_check(f, pts, zp["v"]) == 0 and orc.Ccs(other).final_check(f, pts, zp["v"]) == orc.ORC_ERR_PROOF
+    # a flipped byte in the PCS proof, a wrong evaluation, a tampered round message
+    bad = dict(proof, zip_proof=dict(zp, pcs_proof=zp["pcs_proof"].copy()))
+    bad["zip_proof"]["pcs_proof"][zp["pcs_proof"].size // 3] ^= 1
+    with pytest.raises(pcs.InvalidPcsOpen):
+        verifier.verify(*_args(inst), bad, fresh(), field)
+    wrong_v = zp["v"].copy()
+    wrong_v[0] ^= np.uint64(1)
+    with pytest.raises(pcs.InvalidPcsOpen, match="Evaluation consistency failure"):
+        verifier.verify(*_args(inst), dict(proof, zip_proof=dict(zp, v=wrong_v)), fresh(), field)
+    m2 = proof["msgs2"].copy()
+    m2[1, 0, 0] ^= np.uint64(1)
+    with pytest.raises(pcs.SpartanError):
+        verifier.verify(*_args(inst), dict(proof, msgs2=m2), fresh(), field)
+    # with the circuit prepared once
+    prep = pcs.ZincProver().prepare(inst.matrices, inst.s, field)
+    verifier.verify(*_args(inst), proof, fresh(), field, prepared=prep)

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "zip_ctx_set_profiling", "zip_ctx_profile_read", "zip_verify", "zip_mle_eval", "zip_field_map_int256",
     "zip_open_stream", "zip_sumcheck_init", "zip_sumcheck_round", "zip_sumcheck_last_error", "zip_sumcheck_free",
     "zip_ccs_create", "zip_ccs_free", "zip_ccs_last_error", "zip_ccs_set_z", "zip_ccs_eq_table",
-    "zip_ccs_second_table", "zip_ccs_table", "zip_ccs_download",
+    "zip_ccs_second_table", "zip_ccs_table", "zip_ccs_download", "zip_ccs_eval_matrices",
 )
 
 
@@ -154,6 +154,7 @@ def lib():
     L.zip_ccs_eq_table.argtypes = [vp, u64p, C.c_uint32]
     L.zip_ccs_second_table.argtypes = [vp, u64p, u64p, u64p]
     L.zip_ccs_table.argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(vp)]
+    L.zip_ccs_eval_matrices.argtypes = [vp, u64p, u64p, u64p]
     L.zip_ccs_download.argtypes = [vp, C.c_int, C.c_uint32, u64p]
     L.zip_commitment_free.argtypes = [vp]
     L.zip_commitment_free.restype = None
@@ -554,6 +555,16 @@ class Ccs:
         self._check(lib().zip_ccs_second_table(self._h, r_x.ctypes.data, gamma.ctypes.data, vs.ctypes.data),
                     "zip_ccs_second_table")
         return vs
+
+    def eval_matrices(self, r_x, r_y):
+        """mle[M_k](r_x, r_y) for every matrix -> [t, limbs]"""
+        r_x = np.ascontiguousarray(r_x, dtype=np.uint64)
+        r_y = np.ascontiguousarray(r_y, dtype=np.uint64)
+        assert r_x.shape == r_y.shape == (self.s, self.field.limbs)
+        out = np.zeros((self.t, self.field.limbs), dtype=np.uint64)
+        self._check(lib().zip_ccs_eval_matrices(self._h, r_x.ctypes.data, r_y.ctypes.data, out.ctypes.data),
+                    "zip_ccs_eval_matrices")
+        return out
 
     def table(self, which, index=0) -> int:
         """Device address of a table of 2^s field elements."""

@@ -8,6 +8,7 @@
 //   second_table_kernel      sum_k gamma^k * compute_eval_table_sparse(M_k, eq(r_x))
 //                                                              sparse_matrix.rs:165-182 + prover.rs:279-290
 //   field_dot_partials_kernel  V_s[k] = Mz_k(r_x) = <Mz_k, eq(r_x)>   prover.rs:330-347
+//   matrix_eval_partials_kernel  mle[M_k](r_x, r_y), the verifier's V_xy   verifier.rs:248-261
 //
 // All of it is exact arithmetic on canonical Montgomery residues, so summation order is free and the
 // results are the reference's bit for bit.  The matrices are CSR for M z (one thread per row) and the
@@ -175,6 +176,50 @@ __global__ void __launch_bounds__(256) second_table_kernel(SecondTableArgs a, co
         for (int i = 0; i < FL; i++) lin[i] = t[i];
     }
     fe_store<FL>(a.out + (size_t)col * FL, lin);
+}
+
+// mle[M](r_x, r_y) = sum_{row, e} eq_x[row] (x) M[row][col_e] (x) eq_y[col_e]
+// (DenseMultilinearExtension::from_matrix + evaluate, src/poly_f/mle/dense.rs:69-87: index = rows * col + row, the
+// low s variables select the row).  One thread per row, block sums to `partials`, then sumcheck_reduce_kernel.
+template <int FL>
+__global__ void __launch_bounds__(256) matrix_eval_partials_kernel(const uint32_t *row_ptr, const uint32_t *col_idx,
+                                                                   const uint64_t *vals, const uint64_t *eq_x,
+                                                                   const uint64_t *eq_y, uint32_t n_rows, uint64_t *partials,
+                                                                   FieldDev<FL> f) {
+    __shared__ uint64_t red[256 * FL];
+    const uint32_t tid = threadIdx.x;
+    uint64_t acc[FL];
+#pragma unroll
+    for (int i = 0; i < FL; i++) acc[i] = 0;
+    for (uint32_t row = blockIdx.x * blockDim.x + tid; row < n_rows; row += gridDim.x * blockDim.x) {
+        uint64_t inner[FL];
+#pragma unroll
+        for (int i = 0; i < FL; i++) inner[i] = 0;
+        for (uint32_t e = row_ptr[row]; e < row_ptr[row + 1]; e++) {
+            uint64_t v[FL], y[FL], t[FL];
+            fe_load<FL>(v, vals + (size_t)e * FL);
+            fe_load<FL>(y, eq_y + (size_t)col_idx[e] * FL);
+            mont_mul<FL>(v, y, f, t);
+            fe_add<FL>(inner, t, f);
+        }
+        uint64_t x[FL], t[FL];
+        fe_load<FL>(x, eq_x + (size_t)row * FL);
+        mont_mul<FL>(inner, x, f, t);
+        fe_add<FL>(acc, t, f);
+    }
+    fe_store<FL>(red + (size_t)tid * FL, acc);
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            uint64_t p[FL], q[FL];
+            fe_load<FL>(p, red + (size_t)tid * FL);
+            fe_load<FL>(q, red + (size_t)(tid + s) * FL);
+            fe_add<FL>(p, q, f);
+            fe_store<FL>(red + (size_t)tid * FL, p);
+        }
+        __syncthreads();
+    }
+    if (tid < FL) partials[(size_t)blockIdx.x * FL + tid] = red[tid];
 }
 
 // partials[block] = sum over the block's share of a[i] (x) b[i]; summed by sumcheck_reduce_kernel (ne = 1)

@@ -1154,6 +1154,21 @@ int32_t ccs_second_fl(zip_ccs *c, const uint64_t *gamma_d, uint64_t *vs_d, const
     return ZIP_OK;
 }
 
+template <int FL>
+int32_t ccs_eval_matrices_fl(zip_ccs *c, uint64_t *out_d, const HostField &hf) {
+    zip_ctx *ctx = c->ctx;
+    const FieldDev<FL> fd = to_dev<FL>(hf);
+    for (uint32_t k = 0; k < c->t; k++) {
+        LaunchTimer t(ctx, "matrix_eval_partials_kernel");
+        hipLaunchKernelGGL(matrix_eval_partials_kernel<FL>, dim3(c->dot_blocks), dim3(256), 0, ctx->stream, c->mat[k].row_ptr,
+                           c->mat[k].col_idx, c->mat[k].vals, c->eq[0], c->eq[1], c->mat[k].n_rows, c->partials, fd);
+        hipLaunchKernelGGL(sumcheck_reduce_kernel<FL>, dim3(1), dim3(256), 0, ctx->stream, c->partials, c->dot_blocks, 1u,
+                           out_d + (size_t)k * FL, fd);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return ZIP_OK;
+}
+
 #define CCS_DISPATCH_FL(fl, fn, ...)                  \
     switch (fl) {                                     \
         case 2: rc = fn<2>(__VA_ARGS__); break;       \
@@ -2296,6 +2311,25 @@ int32_t zip_ccs_second_table(zip_ccs *c, const uint64_t *r_x, const uint64_t *ga
     HIP_TRY(ctx, hipMemcpyAsync(v_s_out, vs_d, (size_t)c->t * c->fl * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     c->have_second = true;
+    return ZIP_OK;
+}
+
+int32_t zip_ccs_eval_matrices(zip_ccs *c, const uint64_t *r_x, const uint64_t *r_y, uint64_t *v_xy_out) {
+    if (!c || !r_x || !r_y || !v_xy_out) return ZIP_ERR_NULL;
+    zip_ctx *ctx = c->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
+    int32_t rc;
+    if ((rc = zip_ccs_eq_table(c, r_x, 0))) return rc;  // both eq slots are overwritten
+    if ((rc = zip_ccs_eq_table(c, r_y, 1))) return rc;
+    c->have_second = false;
+    HostField hf;
+    if ((rc = ccs_field(c, &hf))) return rc;
+    uint64_t *out_d = c->small_d + (size_t)33 * 8;
+    CCS_DISPATCH_FL(c->fl, ccs_eval_matrices_fl, c, out_d, hf);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(v_xy_out, out_d, (size_t)c->t * c->fl * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ZIP_OK;
 }
 

@@ -20,6 +20,9 @@ int32_t guarded(F &&f) {
     try {
         f();
         return ZINC_OK;
+    } catch (const zinc::SpartanError &e) {
+        g_err = e.what();
+        return ZINC_ERR_SPARTAN;
     } catch (const ZipError &e) {
         g_err = e.what();
         return e.kind == ZipError::InvalidPcsParam ? ZINC_ERR_INVALID_PARAM
@@ -410,6 +413,61 @@ int32_t zinc_prover_prove(const zip_sparse_matrix *constraints, uint32_t t, uint
             for (uint32_t e = 0; e < 3; e++) put(msgs2_out + (r * 3 + e) * limbs, sp.second_sumcheck.msgs[r][e]);
         for (size_t k = 0; k < sp.V_s.size(); k++) put(v_s_out + k * limbs, sp.V_s[k]);
         for (size_t i = 0; i < r_y.size(); i++) put(r_y_out + i * limbs, r_y[i]);
+    });
+}
+
+int32_t zinc_verifier_verify(const zip_sparse_matrix *constraints, uint32_t t, uint32_t s, uint32_t d, uint32_t q,
+                             const uint32_t *s_masks, const int64_t *c, zinc_transcript *transcript, const uint64_t *modulus,
+                             uint32_t limbs, int32_t device, zinc_prepared_ccs *prepared, const uint64_t *msgs1,
+                             const uint64_t *msgs2, const uint64_t *v_s, int32_t with_pcs, const uint8_t *roots,
+                             size_t n_roots, const uint64_t *v, const uint8_t *pcs_proof, size_t pcs_proof_len,
+                             uint64_t *rx_ry_out, uint64_t *e_y_out, uint64_t *gamma_out) {
+    if ((!constraints && !prepared && with_pcs) || !s_masks || !c || !transcript || !msgs1 || !msgs2 || !v_s ||
+        (with_pcs && (!roots || !v || !pcs_proof)))
+        return ZINC_ERR_NULL;
+    return guarded([&] {
+        const FieldConfig f = FieldConfig::make(modulus, limbs);
+        zinc::ccs::CCS_Z ccs = square_ccs(t, s);
+        ccs.q = q;
+        ccs.d = d;
+        for (uint32_t i = 0; i < q; i++) {
+            ccs.c.push_back(c[i]);
+            ccs.S.emplace_back();
+            for (uint32_t j = 0; j < 32; j++)
+                if ((s_masks[i] >> j) & 1u) ccs.S.back().push_back(j);
+        }
+        zinc::SpartanProof sp;
+        auto take = [&](const uint64_t *src, size_t rounds, size_t per) {
+            zinc::sumcheck::SumcheckProof p;
+            for (size_t r = 0; r < rounds; r++) {
+                p.msgs.emplace_back();
+                for (size_t e = 0; e < per; e++) p.msgs.back().push_back(load(src + (r * per + e) * limbs, limbs));
+            }
+            return p;
+        };
+        sp.linearization_sumcheck = take(msgs1, s, d + 2);
+        sp.second_sumcheck = take(msgs2, s, 3);
+        for (uint32_t k = 0; k < t; k++) sp.V_s.push_back(load(v_s + (size_t)k * limbs, limbs));
+        const zinc::ZincVerifier verifier(LinearCodeSpec{}, device);
+        const zinc::VerificationPoints pts = verifier.spartan_verify(sp, ccs, transcript->t, f);
+        auto put = [&](uint64_t *dst, const Limbs &x) {
+            if (dst)
+                for (uint32_t i = 0; i < limbs; i++) dst[i] = x[i];
+        };
+        if (rx_ry_out)
+            for (size_t i = 0; i < pts.rx_ry.size(); i++) put(rx_ry_out + i * limbs, pts.rx_ry[i]);
+        put(e_y_out, pts.e_y);
+        put(gamma_out, pts.gamma);
+        if (!with_pcs) return;
+        zinc::ccs::Statement_Z st;
+        if (prepared) st.constraints.resize(t);
+        else st = statement_from_abi(constraints, t);
+        zinc::zip::ZipProof zp;
+        zp.z_comm.roots.resize(n_roots);
+        std::memcpy(zp.z_comm.roots.data(), roots, n_roots * 32);
+        zp.v = load(v, limbs);
+        zp.pcs_proof.assign(pcs_proof, pcs_proof + pcs_proof_len);
+        verifier.verify_pcs_proof(st, zp, pts, ccs, transcript->t, f, prepared ? prepared->p.get() : nullptr);
     });
 }
 

@@ -239,6 +239,19 @@ void FieldConfig::neg(Limbs &a) const {
     a = t;
 }
 
+Limbs FieldConfig::inverse(const Limbs &a) const {
+    Limbs e = modulus, two{};
+    two[0] = 2;
+    sub_in_place(e, two, limbs);  // q - 2
+    Limbs acc = r, base = a;
+    for (uint32_t i = 0; i < 64 * limbs; i++) {
+        if ((e[i / 64] >> (i % 64)) & 1) mul_assign(acc, base);
+        const Limbs sq = base;
+        mul_assign(base, sq);
+    }
+    return acc;
+}
+
 uint32_t FieldConfig::num_bits() const { return bit_length(modulus, limbs); }
 
 zip_field FieldConfig::to_abi() const {
@@ -1048,6 +1061,166 @@ ZincProof ZincProver::prove_z(const ccs::Statement_Z &statement, const int64_t *
     timer.lap("commit_z_mle_and_prove_eval");
     if (r_y_out) *r_y_out = std::move(r_y);
     return out;
+}
+
+// ---------------------------------------------------------------------------- sumcheck verifier
+Limbs sumcheck::interpolate_uni_poly(const FieldConfig &config, const std::vector<Limbs> &p_i, const Limbs &x) {
+    const size_t len = p_i.size();
+    std::vector<Limbs> evals{x};
+    Limbs prod = x, j{};
+    for (size_t i = 1; i < len; i++) {  // verifier.rs:176-185: early return when x is one of the nodes
+        if (x == j) return p_i[i - 1];
+        config.add_assign(j, config.r);
+        Limbs tmp = x;
+        config.sub_assign(tmp, j);
+        evals.push_back(tmp);
+        config.mul_assign(prod, tmp);
+    }
+    if (x == j) return p_i[len - 1];
+    // sum_i p_i[i] * prod / ((x - i) * prod_{k != i} (i - k)): the reference only organises the denominators
+    // so that it needs fewer divisions (:217-300); the value is that of the unique interpolant either way
+    Limbs res{};
+    for (size_t i = 0; i < len; i++) {
+        Limbs den = config.r;
+        for (size_t k = 0; k < len; k++)
+            if (k != i) config.mul_assign(den, map_to_field(config, (int64_t)i - (int64_t)k));
+        config.mul_assign(den, evals[i]);
+        Limbs term = config.inverse(den);
+        config.mul_assign(term, prod);
+        config.mul_assign(term, p_i[i]);
+        config.add_assign(res, term);
+    }
+    return res;
+}
+
+sumcheck::SubClaim sumcheck::verify_as_subprotocol(KeccakTranscript &transcript, uint32_t num_vars, uint32_t degree,
+                                                   const Limbs &claimed_sum, const SumcheckProof &proof,
+                                                   const FieldConfig &config) {
+    transcript.absorb_random_field(config, map_to_field_u128(config, num_vars, 0));  // sumcheck.rs:124-136
+    transcript.absorb_random_field(config, map_to_field_u128(config, degree, 0));
+    SubClaim claim;
+    if (num_vars == 0) {  // :138-144
+        transcript.absorb_random_field(config, claimed_sum);
+        claim.expected_evaluation = claimed_sum;
+        return claim;
+    }
+    if (proof.msgs.size() != num_vars)
+        throw SpartanError(SpartanError::InvalidProofLength, "sumcheck proof has " + std::to_string(proof.msgs.size()) +
+                                                                 " rounds, expected " + std::to_string(num_vars));
+    for (uint32_t i = 0; i < num_vars; i++) {  // :155-160, verify_round (verifier.rs:61-90)
+        for (const Limbs &e : proof.msgs[i]) transcript.absorb_random_field(config, e);
+        const Limbs r = transcript.get_challenge(config);
+        transcript.absorb_random_field(config, r);
+        claim.point.push_back(r);
+    }
+    Limbs expected = claimed_sum;  // check_and_generate_subclaim (verifier.rs:97-143)
+    for (uint32_t i = 0; i < num_vars; i++) {
+        const std::vector<Limbs> &ev = proof.msgs[i];
+        if (ev.size() != (size_t)degree + 1) throw SpartanError(SpartanError::MaxDegreeExceeded, "MaxDegreeExceeded");
+        Limbs sum = ev[0];
+        if (degree > 0) config.add_assign(sum, ev[1]);
+        if (sum != expected) throw SpartanError(SpartanError::SumCheckFailed, "sumcheck round " + std::to_string(i) + ": p(0) + p(1) != expected");
+        expected = interpolate_uni_poly(config, ev, claim.point[i]);
+    }
+    claim.expected_evaluation = expected;
+    return claim;
+}
+
+// ---------------------------------------------------------------------------- ZincVerifier
+namespace {
+Limbs lin_comb_V_s(const FieldConfig &config, const Limbs &gamma, const std::vector<Limbs> &V) {  // verifier.rs:212-219
+    Limbs res{};
+    for (size_t i = V.size(); i-- > 0;) {
+        config.mul_assign(res, gamma);
+        config.add_assign(res, V[i]);
+    }
+    return res;
+}
+}  // namespace
+
+VerificationPoints ZincVerifier::spartan_verify(const SpartanProof &proof, const ccs::CCS_Z &ccs, KeccakTranscript &transcript,
+                                                const FieldConfig &config) const {
+    if (proof.V_s.size() != ccs.t || ccs.S.size() != ccs.q || ccs.c.size() != ccs.q)
+        throw std::logic_error("index out of bounds: V_s / ccs.S / ccs.c sizes");  // the reference indexes V_s[j]
+    transcript.absorb(reinterpret_cast<const uint8_t *>("beta_s"), 6);
+    std::vector<Limbs> beta_s;
+    for (size_t i = 0; i < ccs.s; i++) beta_s.push_back(transcript.get_challenge(config));
+    // verify_linearization_proof (:142-162): degree d + 1, claimed sum 0
+    const sumcheck::SubClaim first = sumcheck::verify_as_subprotocol(transcript, (uint32_t)ccs.s, (uint32_t)ccs.d + 1, Limbs{},
+                                                                    proof.linearization_sumcheck, config);
+    // verify_linearization_claim (:164-187)
+    Limbs e = config.r;
+    for (size_t i = 0; i < ccs.s; i++) {  // eq_eval, sumcheck/utils.rs:81-95
+        Limbs xy = first.point[i];
+        config.mul_assign(xy, beta_s[i]);
+        Limbs term = xy;
+        config.add_assign(term, xy);
+        config.sub_assign(term, first.point[i]);
+        config.sub_assign(term, beta_s[i]);
+        config.add_assign(term, config.r);
+        config.mul_assign(e, term);
+    }
+    Limbs sum{};
+    for (size_t i = 0; i < ccs.q; i++) {
+        Limbs term = map_to_field(config, ccs.c[i]);
+        for (size_t j : ccs.S[i]) {
+            if (j >= proof.V_s.size()) throw std::logic_error("index out of bounds: ccs.S refers to a missing V_s");
+            config.mul_assign(term, proof.V_s[j]);
+        }
+        config.add_assign(sum, term);
+    }
+    config.mul_assign(e, sum);
+    if (e != first.expected_evaluation) throw SpartanError(SpartanError::SumCheckFailed, "linearization claim: e * sum c_i prod V_s != s");
+    VerificationPoints out;
+    transcript.absorb(reinterpret_cast<const uint8_t *>("gamma"), 5);
+    out.gamma = transcript.get_challenge(config);
+    const Limbs claimed = lin_comb_V_s(config, out.gamma, proof.V_s);
+    const sumcheck::SubClaim second = sumcheck::verify_as_subprotocol(transcript, (uint32_t)ccs.s_prime, 2, claimed,
+                                                                     proof.second_sumcheck, config);  // :189-210
+    out.rx_ry = first.point;
+    out.rx_ry.insert(out.rx_ry.end(), second.point.begin(), second.point.end());
+    out.e_y = second.expected_evaluation;
+    return out;
+}
+
+void ZincVerifier::verify_pcs_proof(const ccs::Statement_Z &statement, const zip::ZipProof &zip_proof,
+                                    const VerificationPoints &points, const ccs::CCS_Z &ccs, KeccakTranscript &transcript,
+                                    const FieldConfig &config, PreparedCcs *prepared) const {
+    if (points.rx_ry.size() != ccs.s + ccs.s_prime) throw std::logic_error("range end index out of range for rx_ry");
+    zip::KeccakSeedSource seeds(transcript);
+    const zip::RaaCode linear_code = zip::RaaCode::make(lc_spec_, ccs.m, seeds);                  // :234
+    const zip::MultilinearZipParams param = zip::MultilinearZip::setup(ccs.m, linear_code, device_);  // :235
+    zip::PcsTranscript pcs_transcript = zip::PcsTranscript::from_proof(zip_proof.pcs_proof.data(), zip_proof.pcs_proof.size());
+    const Limbs *r_y = points.rx_ry.data() + ccs.s;
+    zip::MultilinearZip::verify(param, zip_proof.z_comm, r_y, ccs.s_prime, zip_proof.v, pcs_transcript, config);  // :239-246
+    // V_xy (:248-261) on the device
+    std::unique_ptr<PreparedCcs> own;
+    if (!prepared) {
+        own = std::make_unique<PreparedCcs>(statement, ccs, config, device_);
+        prepared = own.get();
+    }
+    std::vector<uint64_t> rx((size_t)ccs.s * config.limbs), ry((size_t)ccs.s_prime * config.limbs), vxy((size_t)ccs.t * config.limbs);
+    for (size_t i = 0; i < ccs.s; i++) std::copy(points.rx_ry[i].begin(), points.rx_ry[i].begin() + config.limbs, rx.begin() + i * config.limbs);
+    for (size_t i = 0; i < ccs.s_prime; i++) std::copy(r_y[i].begin(), r_y[i].begin() + config.limbs, ry.begin() + i * config.limbs);
+    {
+        std::lock_guard<std::mutex> one(prepared->mu_);
+        ccs_check(prepared->h_, zip_ccs_eval_matrices(prepared->h_, rx.data(), ry.data(), vxy.data()), "zip_ccs_eval_matrices");
+    }
+    std::vector<Limbs> V_xy(ccs.t);
+    for (size_t k = 0; k < ccs.t; k++)
+        for (uint32_t i = 0; i < config.limbs; i++) V_xy[k][i] = vxy[k * config.limbs + i];
+    Limbs lhs = lin_comb_V_s(config, points.gamma, V_xy);  // :264
+    config.mul_assign(lhs, zip_proof.v);
+    if (lhs != points.e_y)
+        throw SpartanError(SpartanError::PcsVerification, "linear combination of powers of gamma and V_x != e_y");
+}
+
+void ZincVerifier::verify(const ccs::Statement_Z &statement, const ZincProof &proof, KeccakTranscript &transcript,
+                          const ccs::CCS_Z &ccs, const FieldConfig &config, PreparedCcs *prepared) const {
+    if (ccs.s == 0 || ccs.s > 28 || ccs.m != ((size_t)1 << ccs.s) || ccs.n != ccs.m || ccs.s_prime != ccs.s)
+        throw std::logic_error("m == n == 2^s is required (see ZincProver)");
+    const VerificationPoints points = spartan_verify(proof.spartan_proof, ccs, transcript, config);  // :62-64
+    verify_pcs_proof(statement, proof.zip_proof, points, ccs, transcript, config, prepared);          // :66-73
 }
 
 }  // namespace zinc

@@ -99,6 +99,7 @@ struct FieldConfig {
     void add_assign(Limbs &a, const Limbs &b) const;                   // config.rs:53-58
     void sub_assign(Limbs &a, const Limbs &b) const;                   // config.rs:60-66
     void neg(Limbs &a) const;                                          // arithmetic.rs:130-149
+    Limbs inverse(const Limbs &a) const;                               // a^(q-2): the unique inverse (q prime)
     uint32_t num_bits() const;
     zip_field to_abi() const;
 
@@ -270,7 +271,22 @@ ProverOutput prove_as_subprotocol_ccs(KeccakTranscript &transcript, const std::v
                                       uint32_t nvars, uint32_t degree, const std::vector<Limbs> &c,
                                       const std::vector<std::vector<uint32_t>> &S, const FieldConfig &config,
                                       int device = 0);
+// SumCheckError / SpartanError (src/sumcheck.rs:28-38, src/zinc/errors.rs): what the verifier returns as Err
+struct SpartanError : std::runtime_error {
+    enum Kind { SumCheckFailed, InvalidProofLength, MaxDegreeExceeded, PcsVerification } kind;
+    SpartanError(Kind k, const std::string &what) : std::runtime_error(what), kind(k) {}
+};
+struct SubClaim {  // src/sumcheck/verifier.rs:33-40
+    std::vector<Limbs> point;
+    Limbs expected_evaluation{};
+};
+// interpolate_uni_poly (src/sumcheck/verifier.rs:161-303)
+Limbs interpolate_uni_poly(const FieldConfig &config, const std::vector<Limbs> &p_i, const Limbs &x);
+// MLSumcheck::verify_as_subprotocol (src/sumcheck.rs:116-160); throws SpartanError
+SubClaim verify_as_subprotocol(KeccakTranscript &transcript, uint32_t num_vars, uint32_t degree, const Limbs &claimed_sum,
+                               const SumcheckProof &proof, const FieldConfig &config);
 }  // namespace sumcheck
+using sumcheck::SpartanError;
 
 // ---------------------------------------------------------------------------- CCS (src/ccs/ccs_z.rs)
 namespace ccs {
@@ -328,6 +344,7 @@ class PreparedCcs {
 
   private:
     friend class ZincProver;
+    friend class ZincVerifier;
     zip_ccs *h_ = nullptr;
     std::mutex mu_;
     uint32_t t_ = 0, s_ = 0, limbs_ = 0;
@@ -357,6 +374,33 @@ class ZincProver {
     static IntVec get_z_ccs(const ccs::Statement_Z &statement, const ccs::Witness_Z &wit, const ccs::CCS_Z &ccs) {
         return get_z_ccs(statement.public_input.data(), statement.public_input.size(), wit.w_ccs.data(), wit.w_ccs.size(), ccs.m);
     }
+
+  private:
+    zip::LinearCodeSpec lc_spec_;
+    int device_;
+};
+
+// VerificationPoints (src/zinc/verifier.rs:275-279)
+struct VerificationPoints {
+    std::vector<Limbs> rx_ry;
+    Limbs e_y{}, gamma{};
+};
+// ZincVerifier (src/zinc/verifier.rs).  The sumcheck verifiers are O(s * d) field operations on the host; the
+// Zip verifier and the evaluation of the matrix MLEs at (r_x, r_y) run on the device.  Not mirrored: the
+// draw_random_field check of Verifier::verify (:53-57, prime generation is out of scope).
+class ZincVerifier {
+  public:
+    explicit ZincVerifier(zip::LinearCodeSpec spec = {}, int device = 0) : lc_spec_(spec), device_(device) {}
+    // Verifier::verify (:45-76) without the field check; throws SpartanError / ZipError{InvalidPcsOpen}
+    void verify(const ccs::Statement_Z &statement, const ZincProof &proof, KeccakTranscript &transcript, const ccs::CCS_Z &ccs,
+                const FieldConfig &config, PreparedCcs *prepared = nullptr) const;
+    // SpartanVerifier::verify (:105-139)
+    VerificationPoints spartan_verify(const SpartanProof &proof, const ccs::CCS_Z &ccs, KeccakTranscript &transcript,
+                                      const FieldConfig &config) const;
+    // verify_pcs_proof (:221-273)
+    void verify_pcs_proof(const ccs::Statement_Z &statement, const zip::ZipProof &zip_proof, const VerificationPoints &points,
+                          const ccs::CCS_Z &ccs, KeccakTranscript &transcript, const FieldConfig &config,
+                          PreparedCcs *prepared = nullptr) const;
 
   private:
     zip::LinearCodeSpec lc_spec_;

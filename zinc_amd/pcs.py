@@ -10,7 +10,7 @@ from . import cabi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libzinc_zip.so")
-OK, ERR_INVALID_PARAM, ERR_PANIC, ERR_DEVICE, ERR_NULL, ERR_INVALID_OPEN = 0, -1, -2, -3, -4, -5
+OK, ERR_INVALID_PARAM, ERR_PANIC, ERR_DEVICE, ERR_NULL, ERR_INVALID_OPEN, ERR_SPARTAN = 0, -1, -2, -3, -4, -5, -6
 
 EXPORTED_SYMBOLS = (
     "zinc_last_error", "zinc_transcript_new", "zinc_transcript_free", "zinc_transcript_absorb",
@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = (
     "zinc_pcs_transcript_probe", "zinc_zip_open", "zinc_pcs_transcript_from_proof", "zinc_pcs_transcript_position",
     "zinc_zip_verify", "zinc_zip_evaluate", "zinc_commit_z_mle_and_prove_evaluation", "zinc_zip_proof_len",
     "zinc_zip_proof_num_roots", "zinc_zip_proof_read", "zinc_zip_proof_free", "zinc_zip_release_cached_contexts", "zinc_sumcheck_prove_product", "zinc_sumcheck_prove_ccs", "zinc_zip_data_download", "zinc_zip_data_upload", "zinc_merkle_tree_new",
-    "zinc_prover_prove", "zinc_prover_prepare", "zinc_prepared_ccs_free",
+    "zinc_prover_prove", "zinc_prover_prepare", "zinc_prepared_ccs_free", "zinc_verifier_verify",
 )
 
 
@@ -32,6 +32,10 @@ class InvalidPcsParam(ValueError):
 
 class InvalidPcsOpen(ValueError):
     """zip::Error::InvalidPcsOpen / a transcript read error: the proof is rejected."""
+
+
+class SpartanError(ValueError):
+    """SpartanError / SumCheckError of the verifier (src/zinc/errors.rs)"""
 
 
 class ReferencePanic(AssertionError):
@@ -113,6 +117,9 @@ def lib():
         L.zinc_prover_prepare.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_int32, C.POINTER(vp)]
         L.zinc_prepared_ccs_free.argtypes = [vp]
         L.zinc_prepared_ccs_free.restype = None
+        L.zinc_verifier_verify.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_uint32,
+                                           C.c_int32, vp, vp, vp, vp, C.c_int32, vp, C.c_size_t, vp, vp, C.c_size_t,
+                                           vp, vp, vp]
         _lib = L
     return _lib
 
@@ -127,6 +134,8 @@ def _check(rc):
         raise InvalidPcsOpen(msg)
     if rc == ERR_PANIC:
         raise ReferencePanic(msg)
+    if rc == ERR_SPARTAN:
+        raise SpartanError(msg)
     raise DeviceError(msg)
 
 
@@ -491,6 +500,47 @@ class ZincProver:
               prepared=None):
         """Prover::prove (prover.rs:50-88) -> ZincProof {spartan_proof, zip_proof}."""
         return self._run(matrices, s, d, S, c, public_input, w_ccs, transcript, field, True, prepared)
+
+
+class ZincVerifier:
+    """ZincVerifier (src/zinc/verifier.rs) without the draw_random_field check of Verifier::verify."""
+
+    def __init__(self, device: int = 0):
+        self.device = device
+
+    def _run(self, matrices, s, d, S, c, proof, transcript, field, with_pcs, prepared):
+        t, fl = len(matrices), field.limbs
+        arr, _keep = ZincProver._abi_matrices(matrices)
+        masks = np.array([sum(1 << j for j in Si) for Si in S], dtype=np.uint32)
+        cv = np.array(c, dtype=np.int64)
+        m1 = np.ascontiguousarray(proof["msgs1"], dtype=np.uint64)
+        m2 = np.ascontiguousarray(proof["msgs2"], dtype=np.uint64)
+        vs = np.ascontiguousarray(proof["V_s"], dtype=np.uint64)
+        assert m1.shape == (s, d + 2, fl) and m2.shape == (s, 3, fl) and vs.shape == (t, fl)
+        pts = dict(rx_ry=np.zeros((2 * s, fl), np.uint64), e_y=np.zeros(fl, np.uint64), gamma=np.zeros(fl, np.uint64))
+        roots = v = pp = None
+        if with_pcs:
+            zp = proof["zip_proof"]
+            roots = np.ascontiguousarray(zp["z_comm"], dtype=np.uint8)
+            v = np.ascontiguousarray(zp["v"], dtype=np.uint64)
+            pp = np.ascontiguousarray(zp["pcs_proof"], dtype=np.uint8)
+        _check(lib().zinc_verifier_verify(arr, t, s, d, len(S), masks.ctypes.data, cv.ctypes.data, transcript._h,
+                                          field._m.ctypes.data, fl, self.device,
+                                          prepared._h if prepared is not None else None, m1.ctypes.data, m2.ctypes.data,
+                                          vs.ctypes.data, 1 if with_pcs else 0,
+                                          roots.ctypes.data if with_pcs else None, roots.shape[0] if with_pcs else 0,
+                                          v.ctypes.data if with_pcs else None, pp.ctypes.data if with_pcs else None,
+                                          pp.size if with_pcs else 0, pts["rx_ry"].ctypes.data, pts["e_y"].ctypes.data,
+                                          pts["gamma"].ctypes.data))
+        return pts
+
+    def spartan_verify(self, matrices, s, d, S, c, proof, transcript: KeccakTranscript, field: FieldConfig):
+        """SpartanVerifier::verify (verifier.rs:105-139) -> VerificationPoints; raises SpartanError."""
+        return self._run(matrices, s, d, S, c, proof, transcript, field, False, None)
+
+    def verify(self, matrices, s, d, S, c, proof, transcript: KeccakTranscript, field: FieldConfig, prepared=None):
+        """Verifier::verify (verifier.rs:45-76); raises SpartanError / InvalidPcsOpen."""
+        return self._run(matrices, s, d, S, c, proof, transcript, field, True, prepared)
 
 
 class PreparedCcs:
