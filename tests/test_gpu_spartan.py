@@ -329,3 +329,62 @@ def test_zinc_prove_then_verify_on_the_device(mods, q, fl, log_n):
     # with the circuit prepared once
     prep = pcs.ZincProver().prepare(inst.matrices, inst.s, field)
     verifier.verify(*_args(inst), proof, fresh(), field, prepared=prep)
+
+
+def test_zinc_prover_at_2_pow_20_constraints(mods):
+    """BASELINE configs[4] at its full size: the spartan_benches.rs instance with 2^20 constraints, Stark prime.
+    SpartanProver::prove equals the oracle's message for message; Prover::prove -> Verifier::verify round trip on the
+    device with the circuit prepared once; the PCS proof has the reference's length (commit.rs:712-775)."""
+    _, pcs = mods
+    log_n = 20
+    inst = _ccs.dummy_ccs_from_len(1 << log_n)
+    f = orc.make_field(QSTARK, 4)
+    field = pcs.FieldConfig(QSTARK, 4)
+    want = orc.Ccs(inst).spartan_prove(f, orc.new_transcript())
+    prover = pcs.ZincProver()
+    prep = prover.prepare(inst.matrices, inst.s, field)
+    x, w = inst.z[:1], inst.z[2:]
+    proof = prover.prove(*_args(inst), x, w, pcs.KeccakTranscript(), field, prepared=prep)
+    for key in ("msgs1", "msgs2", "V_s", "r_y"):
+        assert np.array_equal(proof[key], want[key]), key
+    row_len, num_rows, depth = 1024, 1024, 11
+    assert proof["zip_proof"]["pcs_proof"].size == row_len * 64 + 1000 * num_rows * (32 + 8 + 32 * depth) + row_len * 32
+    pts = pcs.ZincVerifier().verify(*_args(inst), proof, pcs.KeccakTranscript(), field, prepared=prep)
+    assert np.array_equal(pts["rx_ry"][log_n:], want["r_y"])
+    bad = dict(proof, V_s=proof["V_s"].copy())
+    bad["V_s"][0, 0] ^= np.uint64(1)
+    with pytest.raises(pcs.SpartanError):
+        pcs.ZincVerifier().verify(*_args(inst), bad, pcs.KeccakTranscript(), field, prepared=prep)
+
+
+def test_one_prepared_circuit_shared_by_concurrent_provers(mods):
+    """Proofs from several threads over the same PreparedCcs are serialised inside and stay correct."""
+    import threading
+
+    _, pcs = mods
+    field = pcs.FieldConfig(Q192, 3)
+    f = orc.make_field(Q192, 3)
+    base = _ccs.vitalik_ccs(3)
+    prover = pcs.ZincProver()
+    prep = prover.prepare(base.matrices, base.s, field)
+    xs = [2, 3, 4, 5, 6, 7]
+    out, errs = {}, []
+
+    def work(x):
+        try:
+            inst = _ccs.vitalik_ccs(x)
+            for _ in range(3):
+                out[x] = prover.spartan_prove(*_args(inst), inst.z[:1], inst.z[2:], pcs.KeccakTranscript(), field, prepared=prep)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(x,)) for x in xs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for x in xs:
+        want = orc.Ccs(_ccs.vitalik_ccs(x)).spartan_prove(f, orc.new_transcript())
+        for key in ("msgs1", "msgs2", "V_s", "r_y"):
+            assert np.array_equal(out[x][key], want[key]), (x, key)
