@@ -63,6 +63,10 @@ struct SumcheckRoundArgs {
     uint32_t n_terms;
     uint32_t term_mask[kSumcheckMaxTerms];
     uint64_t coeff[kSumcheckMaxTerms][FL];
+    // coefficients that are 1 or -1 (every R1CS-shaped CCS: c = [1, -1]) cost no multiplication:
+    // 0 = general, 1 = one, 2 = minus one.  `one` = R mod q, for a term with an empty product.
+    uint32_t coeff_kind[kSumcheckMaxTerms];
+    uint64_t one[FL];
 };
 
 // K = number of MLEs, DEG = degree of the round polynomial (evaluations at 0..DEG); template
@@ -139,19 +143,34 @@ __global__ void __launch_bounds__(256) sumcheck_round_kernel(SumcheckRoundArgs<F
                 for (int i = 0; i < FL; i++) sum[i] = 0;
                 for (uint32_t tt = 0; tt < a.n_terms; tt++) {
                     uint64_t term[FL];
+                    const uint32_t kind = a.coeff_kind[tt];  // wave-uniform
+                    bool have = kind == 0;
+                    if (have) {
 #pragma unroll
-                    for (int i = 0; i < FL; i++) term[i] = a.coeff[tt][i];
+                        for (int i = 0; i < FL; i++) term[i] = a.coeff[tt][i];
+                    }
                     const uint32_t m = a.term_mask[tt];
 #pragma unroll
                     for (int k = 0; k < K; k++) {
                         if ((m >> k) & 1u) {  // wave-uniform
-                            uint64_t t[FL];
-                            mont_mul<FL>(term, val[k], f, t);
+                            if (have) {
+                                uint64_t t[FL];
+                                mont_mul<FL>(term, val[k], f, t);
 #pragma unroll
-                            for (int i = 0; i < FL; i++) term[i] = t[i];
+                                for (int i = 0; i < FL; i++) term[i] = t[i];
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < FL; i++) term[i] = val[k][i];
+                                have = true;
+                            }
                         }
                     }
-                    fe_add<FL>(sum, term, f);
+                    if (!have) {
+#pragma unroll
+                        for (int i = 0; i < FL; i++) term[i] = a.one[i];
+                    }
+                    if (kind == 2) fe_sub<FL>(sum, term, f);
+                    else fe_add<FL>(sum, term, f);
                 }
                 mont_mul<FL>(sum, val[K - 1], f, c);  // eq() is the last MLE
             }

@@ -1049,9 +1049,16 @@ int32_t sumcheck_round_fl(zip_sumcheck *s, const uint64_t *r_prev, const HostFie
     a.fold = round > 1;
     a.partials = s->partials;
     a.n_terms = s->n_terms;
+    uint64_t minus_one[8] = {0};
+    for (int i = 0; i < FL; i++) {
+        a.one[i] = hf.r[i];
+        minus_one[i] = hf.modulus[i];
+    }
+    sub_limbs(minus_one, hf.r, FL);  // q - R
     for (uint32_t t = 0; t < s->n_terms; t++) {
         a.term_mask[t] = s->term_mask[t];
         for (int i = 0; i < FL; i++) a.coeff[t][i] = s->coeff[t][i];
+        a.coeff_kind[t] = !cmp_limbs(s->coeff[t], hf.r, FL) ? 1u : !cmp_limbs(s->coeff[t], minus_one, FL) ? 2u : 0u;
     }
     for (uint32_t k = 0; k < s->n_mles; k++) {
         // round 1 reads the input; round 2 folds input -> buf[0]; round j >= 3 folds buf[j & 1] ... alternating
