@@ -137,6 +137,86 @@ __global__ void __launch_bounds__(256) spmv_rows_kernel(const uint32_t *row_ptr,
     fe_store<FL>(out + (size_t)row * FL, acc);
 }
 
+// ---- transposing a CSR matrix on the device (for second_table_kernel) -------------------------------
+// counts[col + 1] += 1 per entry; an inclusive scan over the m + 1 counters gives col_ptr; then every entry is
+// placed at an atomically advanced per-column cursor.  The order inside a column is whatever the atomics give --
+// the column sums are exact field sums, so it does not matter.
+__global__ void __launch_bounds__(256) csc_count_kernel(const uint32_t *col_idx, uint32_t nnz, uint32_t *counts) {
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += gridDim.x * blockDim.x)
+        atomicAdd(&counts[col_idx[e] + 1], 1u);
+}
+
+constexpr uint32_t kScanBlock = 1024, kScanItems = 4, kScanTile = kScanBlock * kScanItems;
+
+// inclusive scan of one tile in LDS; returns this thread's four results and the tile total
+__device__ __forceinline__ uint32_t tile_inclusive_scan(uint32_t (&v)[kScanItems], uint32_t *lds) {
+    const uint32_t tid = threadIdx.x;
+#pragma unroll
+    for (uint32_t i = 1; i < kScanItems; i++) v[i] += v[i - 1];
+    lds[tid] = v[kScanItems - 1];
+    __syncthreads();
+    for (uint32_t off = 1; off < kScanBlock; off <<= 1) {
+        const uint32_t add = tid >= off ? lds[tid - off] : 0u;
+        __syncthreads();
+        lds[tid] += add;
+        __syncthreads();
+    }
+    const uint32_t before = tid ? lds[tid - 1] : 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < kScanItems; i++) v[i] += before;
+    return lds[kScanBlock - 1];
+}
+
+// phase 1: tile sums; phase 3 (offsets != nullptr): in-place inclusive scan with the tile's offset added
+__global__ void __launch_bounds__(kScanBlock) scan_tiles_kernel(uint32_t *data, uint32_t n, uint32_t *tile_sums,
+                                                                const uint32_t *offsets) {
+    __shared__ uint32_t lds[kScanBlock];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+#pragma unroll
+    for (uint32_t i = 0; i < kScanItems; i++) v[i] = base + i < n ? data[base + i] : 0u;
+    const uint32_t total = tile_inclusive_scan(v, lds);
+    if (offsets) {
+        const uint32_t off = offsets[blockIdx.x];
+#pragma unroll
+        for (uint32_t i = 0; i < kScanItems; i++)
+            if (base + i < n) data[base + i] = v[i] + off;
+    } else if (threadIdx.x == 0) {
+        tile_sums[blockIdx.x] = total;
+    }
+}
+
+// phase 2: exclusive scan of the tile sums (one workgroup, tile after tile)
+__global__ void __launch_bounds__(kScanBlock) scan_sums_kernel(uint32_t *sums, uint32_t n) {
+    __shared__ uint32_t lds[kScanBlock];
+    uint32_t carry = 0;
+    for (uint32_t start = 0; start < n; start += kScanTile) {
+        const uint32_t base = start + threadIdx.x * kScanItems;
+        uint32_t v[kScanItems], orig[kScanItems];
+#pragma unroll
+        for (uint32_t i = 0; i < kScanItems; i++) orig[i] = v[i] = base + i < n ? sums[base + i] : 0u;
+        const uint32_t total = tile_inclusive_scan(v, lds);
+#pragma unroll
+        for (uint32_t i = 0; i < kScanItems; i++)
+            if (base + i < n) sums[base + i] = v[i] - orig[i] + carry;
+        carry += total;
+        __syncthreads();
+    }
+}
+
+template <int FL>
+__global__ void __launch_bounds__(256) csc_fill_kernel(const uint32_t *row_ptr, const uint32_t *col_idx, const uint64_t *vals,
+                                                       uint32_t n_rows, uint32_t *cursor, uint32_t *row_idx, uint64_t *vals_t) {
+    for (uint32_t row = blockIdx.x * blockDim.x + threadIdx.x; row < n_rows; row += gridDim.x * blockDim.x)
+        for (uint32_t e = row_ptr[row]; e < row_ptr[row + 1]; e++) {
+            const uint32_t dst = atomicAdd(&cursor[col_idx[e]], 1u);
+            row_idx[dst] = row;
+            uint64_t v[FL];
+            fe_load<FL>(v, vals + (size_t)e * FL);
+            fe_store<FL>(vals_t + (size_t)dst * FL, v);
+        }
+}
+
 constexpr int kCcsMaxMatrices = 7;
 
 struct SecondTableArgs {

@@ -2172,65 +2172,54 @@ int32_t zip_ccs_create(int32_t device, const zip_sparse_matrix *mats, uint32_t t
         c->fl = hf.fl;
         memcpy(c->modulus, hf.modulus, sizeof c->modulus);
         const size_t elem = (size_t)hf.fl * 8, tab = (size_t)m * elem;
-        static const bool dbg = getenv("ZIP_HIP_DEBUG_TIMING") != nullptr;
-        std::vector<uint32_t> col_ptr, row_idx, next;  // reused by every matrix (fresh pages fault at ~1 GB/s)
-        std::vector<int64_t> vals_t;
-        auto now = [] { return std::chrono::steady_clock::now(); };
-        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-            return std::chrono::duration<double, std::milli>(b - a).count();
-        };
         for (uint32_t k = 0; k < t && rc == ZIP_OK; k++) {
-            const auto t0 = now();
             const zip_sparse_matrix &M = mats[k];
             zip_ccs::Mat &D = c->mat[k];
             const uint32_t nnz = M.row_ptr[M.n_rows];
             D.n_rows = M.n_rows;
             D.nnz = nnz;
-            // the transposed form: a counting sort by column (rows stay ascending inside a column)
-            col_ptr.assign((size_t)m + 1, 0);
-            row_idx.resize(nnz);
-            vals_t.resize(nnz);
-            for (uint32_t e = 0; e < nnz; e++) col_ptr[M.col_idx[e] + 1]++;
-            for (uint32_t col = 0; col < m; col++) col_ptr[col + 1] += col_ptr[col];
-            {
-                next.assign(col_ptr.begin(), col_ptr.end() - 1);
-                for (uint32_t r = 0; r < M.n_rows; r++)
-                    for (uint32_t e = M.row_ptr[r]; e < M.row_ptr[r + 1]; e++) {
-                        const uint32_t dst = next[M.col_idx[e]]++;
-                        row_idx[dst] = r;
-                        vals_t[dst] = M.values[e];
-                    }
-            }
-            const auto t1 = now();
-            void *tmp = nullptr;  // i64 values before the field map
+            void *tmp = nullptr, *cursor = nullptr, *sums = nullptr;
+            const uint32_t n_cnt = m + 1, tiles = (n_cnt + kScanTile - 1) / kScanTile;
             if ((rc = pool_alloc(ctx, (size_t)(M.n_rows + 1) * 4, (void **)&D.row_ptr))) break;
             if ((rc = pool_alloc(ctx, (size_t)nnz * 4, (void **)&D.col_idx))) break;
-            if ((rc = pool_alloc(ctx, ((size_t)m + 1) * 4, (void **)&D.col_ptr))) break;
+            if ((rc = pool_alloc(ctx, (size_t)n_cnt * 4, (void **)&D.col_ptr))) break;
             if ((rc = pool_alloc(ctx, (size_t)nnz * 4, (void **)&D.row_idx))) break;
             if ((rc = pool_alloc(ctx, (size_t)nnz * elem, (void **)&D.vals))) break;
             if ((rc = pool_alloc(ctx, (size_t)nnz * elem, (void **)&D.vals_t))) break;
-            if ((rc = pool_alloc(ctx, (size_t)nnz * 8, &tmp))) break;
-            const auto t2 = now();
+            if ((rc = pool_alloc(ctx, (size_t)nnz * 8, &tmp))) break;       // i64 values before the field map
+            if ((rc = pool_alloc(ctx, (size_t)n_cnt * 4, &cursor))) break;  // per-column write positions
+            if ((rc = pool_alloc(ctx, (size_t)tiles * 4, &sums))) break;
             if ((rc = copy_h2d_bounced(ctx, D.row_ptr, M.row_ptr, (size_t)(M.n_rows + 1) * 4, ctx->stream))) break;
-            if ((rc = copy_h2d_bounced(ctx, D.col_ptr, col_ptr.data(), ((size_t)m + 1) * 4, ctx->stream))) break;
+            if (hipMemsetAsync(D.col_ptr, 0, (size_t)n_cnt * 4, ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
             if (nnz) {
                 if ((rc = copy_h2d_bounced(ctx, D.col_idx, M.col_idx, (size_t)nnz * 4, ctx->stream))) break;
-                if ((rc = copy_h2d_bounced(ctx, D.row_idx, row_idx.data(), (size_t)nnz * 4, ctx->stream))) break;
-                // SparseMatrix::map_to_field (sparse_matrix.rs:38-58), once per order
+                // SparseMatrix::map_to_field (sparse_matrix.rs:38-58)
                 if ((rc = copy_h2d_bounced(ctx, tmp, M.values, (size_t)nnz * 8, ctx->stream))) break;
                 CCS_DISPATCH_FL(hf.fl, ccs_map_i64, ctx, static_cast<const int64_t *>(tmp), nnz, nnz, D.vals, hf);
                 if (rc) break;
-                if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }  // tmp is reused
-                if ((rc = copy_h2d_bounced(ctx, tmp, vals_t.data(), (size_t)nnz * 8, ctx->stream))) break;
-                CCS_DISPATCH_FL(hf.fl, ccs_map_i64, ctx, static_cast<const int64_t *>(tmp), nnz, nnz, D.vals_t, hf);
-                if (rc) break;
+                const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)nnz + 255) / 256, 65535);
+                hipLaunchKernelGGL(csc_count_kernel, dim3(blocks), dim3(256), 0, ctx->stream, D.col_idx, nnz, D.col_ptr);
             }
-            if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
+            // col_ptr = inclusive scan of the counters (counts sit at [col + 1], so col_ptr[0] = 0)
+            hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, D.col_ptr, n_cnt,
+                               static_cast<uint32_t *>(sums), static_cast<const uint32_t *>(nullptr));
+            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kScanBlock), 0, ctx->stream, static_cast<uint32_t *>(sums), tiles);
+            hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(kScanBlock), 0, ctx->stream, D.col_ptr, n_cnt,
+                               static_cast<uint32_t *>(nullptr), static_cast<const uint32_t *>(sums));
+            if (hipMemcpyAsync(cursor, D.col_ptr, (size_t)n_cnt * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
+            if (nnz) {
+                const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)M.n_rows + 255) / 256, 65535);
+                switch (hf.fl) {
+                    case 2: hipLaunchKernelGGL(csc_fill_kernel<2>, dim3(blocks), dim3(256), 0, ctx->stream, D.row_ptr, D.col_idx, D.vals, M.n_rows, static_cast<uint32_t *>(cursor), D.row_idx, D.vals_t); break;
+                    case 3: hipLaunchKernelGGL(csc_fill_kernel<3>, dim3(blocks), dim3(256), 0, ctx->stream, D.row_ptr, D.col_idx, D.vals, M.n_rows, static_cast<uint32_t *>(cursor), D.row_idx, D.vals_t); break;
+                    default: hipLaunchKernelGGL(csc_fill_kernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, D.row_ptr, D.col_idx, D.vals, M.n_rows, static_cast<uint32_t *>(cursor), D.row_idx, D.vals_t); break;
+                }
+            }
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
             pool_release(ctx, tmp);
+            pool_release(ctx, cursor);
+            pool_release(ctx, sums);
             if ((rc = pool_alloc(ctx, tab, (void **)&c->mz[k]))) break;
-            if (dbg)
-                fprintf(stderr, "[zip_ccs_create] matrix %u: transpose %.2f ms, alloc %.2f ms, upload+map %.2f ms\n", k,
-                        ms(t0, t1), ms(t1, t2), ms(t2, now()));
         }
         if (rc) break;
         if ((rc = pool_alloc(ctx, tab, (void **)&c->z_f))) break;

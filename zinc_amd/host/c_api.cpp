@@ -324,20 +324,6 @@ int32_t zinc_sumcheck_prove_ccs(zinc_transcript *transcript, const uint64_t *con
 }
 
 namespace {
-zinc::ccs::Statement_Z statement_from_abi(const zip_sparse_matrix *constraints, uint32_t t) {
-    zinc::ccs::Statement_Z st;
-    for (uint32_t k = 0; k < t; k++) {
-        const zip_sparse_matrix &M = constraints[k];
-        zinc::ccs::SparseMatrix m;
-        m.n_rows = M.n_rows;
-        m.n_cols = M.n_cols;
-        m.row_ptr.assign(M.row_ptr, M.row_ptr + M.n_rows + 1);
-        m.col_idx.assign(M.col_idx, M.col_idx + M.row_ptr[M.n_rows]);
-        m.values.assign(M.values, M.values + M.row_ptr[M.n_rows]);
-        st.constraints.push_back(std::move(m));
-    }
-    return st;
-}
 zinc::ccs::CCS_Z square_ccs(uint32_t t, uint32_t s) {
     zinc::ccs::CCS_Z ccs;
     ccs.m = ccs.n = (size_t)1 << s;
@@ -358,8 +344,7 @@ int32_t zinc_prover_prepare(const zip_sparse_matrix *constraints, uint32_t t, ui
     *out = nullptr;
     return guarded([&] {
         const FieldConfig f = FieldConfig::make(modulus, limbs);
-        const zinc::ccs::Statement_Z st = statement_from_abi(constraints, t);
-        *out = new zinc_prepared_ccs{std::make_unique<zinc::PreparedCcs>(st, square_ccs(t, s), f, device), t, s};
+        *out = new zinc_prepared_ccs{std::make_unique<zinc::PreparedCcs>(constraints, t, s, f, device), t, s};
     });
 }
 void zinc_prepared_ccs_free(zinc_prepared_ccs *p) { delete p; }
@@ -387,10 +372,11 @@ int32_t zinc_prover_prove(const zip_sparse_matrix *constraints, uint32_t t, uint
                 if ((s_masks[i] >> j) & 1u) ccs.S.back().push_back(j);
         }
         zinc::ccs::Statement_Z st;
-        if (prepared) st.constraints.resize(t);  // the matrices are on the device already
-        else st = statement_from_abi(constraints, t);
+        st.constraints.resize(t);  // the matrices go to the device straight from the caller's arrays
         st.public_input.assign(public_input, public_input + l);
-        zinc::PreparedCcs *prep = prepared ? prepared->p.get() : nullptr;
+        std::unique_ptr<zinc::PreparedCcs> own;  // per proof, as the reference maps the matrices per proof
+        if (!prepared) own = std::make_unique<zinc::PreparedCcs>(constraints, t, s, f, device);
+        zinc::PreparedCcs *prep = prepared ? prepared->p.get() : own.get();
         const zinc::IntVec z = zinc::ZincProver::get_z_ccs(public_input, l, w_ccs, w_len, ccs.m);  // x || 1 || w
         const zinc::ZincProver prover(LinearCodeSpec{}, device);
         zinc::SpartanProof sp;
@@ -460,14 +446,15 @@ int32_t zinc_verifier_verify(const zip_sparse_matrix *constraints, uint32_t t, u
         put(gamma_out, pts.gamma);
         if (!with_pcs) return;
         zinc::ccs::Statement_Z st;
-        if (prepared) st.constraints.resize(t);
-        else st = statement_from_abi(constraints, t);
+        st.constraints.resize(t);
+        std::unique_ptr<zinc::PreparedCcs> own;
+        if (!prepared) own = std::make_unique<zinc::PreparedCcs>(constraints, t, s, f, device);
         zinc::zip::ZipProof zp;
         zp.z_comm.roots.resize(n_roots);
         std::memcpy(zp.z_comm.roots.data(), roots, n_roots * 32);
         zp.v = load(v, limbs);
         zp.pcs_proof.assign(pcs_proof, pcs_proof + pcs_proof_len);
-        verifier.verify_pcs_proof(st, zp, pts, ccs, transcript->t, f, prepared ? prepared->p.get() : nullptr);
+        verifier.verify_pcs_proof(st, zp, pts, ccs, transcript->t, f, prepared ? prepared->p.get() : own.get());
     });
 }
 

@@ -950,6 +950,11 @@ PreparedCcs::PreparedCcs(const ccs::Statement_Z &statement, const ccs::CCS_Z &cc
     for (const auto &M : statement.constraints) mats.push_back(M.to_abi());
     ccs_check(nullptr, zip_ccs_create(device, mats.data(), t_, s_, &zf, &h_), "zip_ccs_create");
 }
+PreparedCcs::PreparedCcs(const zip_sparse_matrix *matrices, uint32_t t, uint32_t s, const FieldConfig &config, int device)
+    : t_(t), s_(s), limbs_(config.limbs), modulus_(config.modulus), device_(device) {
+    const zip_field zf = config.to_abi();
+    ccs_check(nullptr, zip_ccs_create(device, matrices, t, s, &zf, &h_), "zip_ccs_create");
+}
 PreparedCcs::~PreparedCcs() { zip_ccs_free(h_); }
 
 std::pair<SpartanProof, std::vector<Limbs>> ZincProver::spartan_prove(const ccs::Statement_Z &statement,

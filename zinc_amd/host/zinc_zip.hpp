@@ -338,6 +338,8 @@ struct ZincProof {
 class PreparedCcs {
   public:
     PreparedCcs(const ccs::Statement_Z &statement, const ccs::CCS_Z &ccs, const FieldConfig &config, int device = 0);
+    // the same from borrowed CSR arrays (t matrices of 2^s columns): nothing is copied on the host
+    PreparedCcs(const zip_sparse_matrix *matrices, uint32_t t, uint32_t s, const FieldConfig &config, int device = 0);
     ~PreparedCcs();
     PreparedCcs(const PreparedCcs &) = delete;
     PreparedCcs &operator=(const PreparedCcs &) = delete;
