@@ -214,16 +214,62 @@ struct FinalizeArgs {
     uint8_t *row_be;      // [row_len][8*FL] big-endian bytes of the Montgomery value, or null
 };
 
+// 32 columns per workgroup, eight threads per column: each sums every eighth chunk (the fold is latency-bound --
+// one thread per column walking all chunks left 16 waves on the whole chip waiting on one load after another),
+// then the eight partial sums meet in LDS and the first thread of the column finishes.
+constexpr uint32_t kFinalizeCols = 32, kFinalizeGroups = 8;
+
 template <int FL, bool DO_INT, bool DO_FIELD>
 __global__ void __launch_bounds__(256) combine_finalize_kernel(FinalizeArgs a, FieldDev<FL> f) {
-    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= a.row_len) return;
+    __shared__ uint64_t sh_int[kFinalizeGroups][kFinalizeCols][3];
+    __shared__ uint64_t sh_a[kFinalizeGroups][kFinalizeCols][FL + 2];
+    __shared__ uint64_t sh_b[kFinalizeGroups][kFinalizeCols][FL + 2];
+    const uint32_t lc = threadIdx.x % kFinalizeCols, g = threadIdx.x / kFinalizeCols;
+    const uint32_t col = blockIdx.x * kFinalizeCols + lc;
+    const bool valid = col < a.row_len;
     if (DO_INT) {
         uint64_t s[3] = {0, 0, 0};
-        for (uint32_t c = 0; c < a.chunks; c++) {
+        if (valid) {
+#pragma unroll 4
+            for (uint32_t c = g; c < a.chunks; c += kFinalizeGroups) {
+                uint64_t t[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) t[i] = a.part_int[((size_t)c * a.row_len + col) * 3 + i];
+                add_n<3>(s, t);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) sh_int[g][lc][i] = s[i];
+    }
+    if (DO_FIELD) {
+        uint64_t A[FL + 2], Bs[FL + 2];
+#pragma unroll
+        for (int i = 0; i < FL + 2; i++) { A[i] = 0; Bs[i] = 0; }
+        if (valid) {
+#pragma unroll 4
+            for (uint32_t c = g; c < a.chunks; c += kFinalizeGroups) {
+                const size_t slot = (size_t)c * a.row_len + col;
+                uint64_t t[FL + 2], u[FL + 2];
+#pragma unroll
+                for (int i = 0; i < FL + 2; i++) t[i] = a.part_a[slot * (FL + 2) + i];
+                u[0] = 0;  // B * 2^64
+#pragma unroll
+                for (int i = 0; i < FL + 1; i++) u[i + 1] = a.part_b[slot * (FL + 1) + i];
+                add_n<FL + 2>(A, t);
+                add_n<FL + 2>(Bs, u);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FL + 2; i++) { sh_a[g][lc][i] = A[i]; sh_b[g][lc][i] = Bs[i]; }
+    }
+    __syncthreads();
+    if (g != 0 || !valid) return;
+    if (DO_INT) {
+        uint64_t s[3] = {0, 0, 0};
+        for (uint32_t k = 0; k < kFinalizeGroups; k++) {
             uint64_t t[3];
 #pragma unroll
-            for (int i = 0; i < 3; i++) t[i] = a.part_int[((size_t)c * a.row_len + col) * 3 + i];
+            for (int i = 0; i < 3; i++) t[i] = sh_int[k][lc][i];
             add_n<3>(s, t);
         }
         const uint64_t sign = (uint64_t)((int64_t)s[2] >> 63);
@@ -236,14 +282,10 @@ __global__ void __launch_bounds__(256) combine_finalize_kernel(FinalizeArgs a, F
         uint64_t A[FL + 2], Bs[FL + 2];
 #pragma unroll
         for (int i = 0; i < FL + 2; i++) { A[i] = 0; Bs[i] = 0; }
-        for (uint32_t c = 0; c < a.chunks; c++) {
-            const size_t slot = (size_t)c * a.row_len + col;
+        for (uint32_t k = 0; k < kFinalizeGroups; k++) {
             uint64_t t[FL + 2], u[FL + 2];
 #pragma unroll
-            for (int i = 0; i < FL + 2; i++) t[i] = a.part_a[slot * (FL + 2) + i];
-            u[0] = 0;  // B * 2^64
-#pragma unroll
-            for (int i = 0; i < FL + 1; i++) u[i + 1] = a.part_b[slot * (FL + 1) + i];
+            for (int i = 0; i < FL + 2; i++) { t[i] = sh_a[k][lc][i]; u[i] = sh_b[k][lc][i]; }
             add_n<FL + 2>(A, t);
             add_n<FL + 2>(Bs, u);
         }

@@ -728,7 +728,7 @@ int32_t run_combine_fl(zip_ctx *ctx, hipStream_t st, const int64_t *evals_d, con
     if (hf) fd = to_dev<FL>(*hf);
     {
         LaunchTimer t(ctx, "combine_finalize_kernel", st);
-        const dim3 grid(bx), block(256);
+        const dim3 grid((C + kFinalizeCols - 1) / kFinalizeCols), block(kFinalizeCols * kFinalizeGroups);
         if (do_int && do_field)
             hipLaunchKernelGGL((combine_finalize_kernel<FL, true, true>), grid, block, 0, st, fa, fd);
         else if (do_int)
