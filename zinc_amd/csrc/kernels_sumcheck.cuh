@@ -58,6 +58,9 @@ struct SumcheckRoundArgs {
     uint32_t degree, fold;
     uint64_t half;                          // number of hypercube points b of this round: 2^(nv - round)
     uint64_t *partials;                     // [gridDim.x][degree + 1][FL]
+    uint32_t *done;                         // arrival counter (zero between launches): the last workgroup folds the
+                                            // partials; nullptr = sumcheck_reduce_kernel does it in a second launch
+    uint64_t *evals_out;                    // [degree + 1][FL], device memory or host-mapped pinned memory
     // combination function: n_terms == 0: the product of all MLE values; otherwise
     //   (sum_t coeff[t] * prod_{j in term_mask[t]} vals[j]) * vals[K - 1]   (zinc/utils.rs:77-94)
     uint32_t n_terms;
@@ -196,6 +199,44 @@ __global__ void __launch_bounds__(256) sumcheck_round_kernel(SumcheckRoundArgs<F
         __syncthreads();
     }
     if (tid < ne * FL) a.partials[(size_t)blockIdx.x * ne * FL + tid] = red[tid];
+    // The workgroup that arrives last folds the per-block partials into the round message (one launch per
+    // round instead of two).  Release: every wave makes its stores visible device-wide before the counter is
+    // bumped; acquire: the folding workgroup fences again before it reads the other workgroups' partials.
+    // Only for small grids: the device-wide release makes every wave write the dirty L2 back, which costs the early
+    // rounds (hundreds of MB of freshly folded tables in the cache) far more than the second launch saves.
+    if (!a.done) return;
+    __shared__ uint32_t is_last;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) is_last = atomicAdd(a.done, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    for (uint32_t e = 0; e < ne; e++) {
+        uint64_t sum[FL];
+#pragma unroll
+        for (int i = 0; i < FL; i++) sum[i] = 0;
+        for (uint32_t b = tid; b < gridDim.x; b += 256) {
+            uint64_t p[FL];
+            fe_load<FL>(p, a.partials + ((size_t)b * ne + e) * FL);
+            fe_add<FL>(sum, p, f);
+        }
+        __syncthreads();  // red is reused
+        fe_store<FL>(red + (size_t)tid * FL, sum);
+        __syncthreads();
+        for (uint32_t s = 128; s > 0; s >>= 1) {
+            if (tid < s) {
+                uint64_t p[FL], q[FL];
+                fe_load<FL>(p, red + (size_t)tid * FL);
+                fe_load<FL>(q, red + (size_t)(tid + s) * FL);
+                fe_add<FL>(p, q, f);
+                fe_store<FL>(red + (size_t)tid * FL, p);
+            }
+            __syncthreads();
+        }
+        if (tid < FL) a.evals_out[(size_t)e * FL + tid] = red[tid];
+    }
+    if (tid == 0) *a.done = 0;  // the next round's launch is ordered after this one on the stream
 }
 
 // evaluations[e] = sum over the blocks' partials (one workgroup; blocks <= a few thousand)

@@ -113,6 +113,8 @@ struct zip_sumcheck {
     bool owned = false;
     uint64_t *buf[2][4] = {};       // ping-pong fold targets: 2^(nv-1) and 2^(nv-2) entries
     uint64_t *partials = nullptr, *evals_d = nullptr;
+    uint32_t *done_d = nullptr;          // arrival counter of the round kernel
+    unsigned char *evals_pinned = nullptr;  // host-mapped slot the round message is written to (or null: evals_d + a copy)
     uint32_t max_blocks = 0;
     uint64_t modulus[8] = {};
     uint32_t n_terms = 0, term_mask[8] = {};  // zip_sumcheck_comb, or n_terms == 0 for the plain product
@@ -206,6 +208,37 @@ void recycle_flush(int device) {
         b = nullptr;
     }
     bin.bounce_cap = 0;
+}
+
+// 256-byte slots of host-mapped pinned memory for results a kernel hands straight to the host (a sumcheck round
+// message is at most 160 bytes): one hipHostMalloc per device, ever.
+constexpr uint32_t kSlabSlots = 256, kSlabSlotBytes = 256;
+struct PinnedSlab {
+    std::mutex mu;
+    unsigned char *base = nullptr;
+    bool used[kSlabSlots] = {};
+};
+PinnedSlab g_slab[kMaxDevices];
+unsigned char *slab_take(int device) {
+    if (device < 0 || device >= kMaxDevices) return nullptr;
+    PinnedSlab &sl = g_slab[device];
+    std::lock_guard<std::mutex> g(sl.mu);
+    if (!sl.base && hipHostMalloc((void **)&sl.base, (size_t)kSlabSlots * kSlabSlotBytes, hipHostMallocDefault) != hipSuccess) {
+        sl.base = nullptr;
+        return nullptr;
+    }
+    for (uint32_t i = 0; i < kSlabSlots; i++)
+        if (!sl.used[i]) {
+            sl.used[i] = true;
+            return sl.base + (size_t)i * kSlabSlotBytes;
+        }
+    return nullptr;
+}
+void slab_give(int device, unsigned char *p) {
+    if (!p || device < 0 || device >= kMaxDevices) return;
+    PinnedSlab &sl = g_slab[device];
+    std::lock_guard<std::mutex> g(sl.mu);
+    sl.used[(p - sl.base) / kSlabSlotBytes] = false;
 }
 
 int32_t pool_alloc(zip_ctx *ctx, size_t bytes, void **out) {
@@ -1021,10 +1054,10 @@ int32_t launch_sumcheck_round(zip_sumcheck *s, const SumcheckRoundArgs<FL> &a, u
         hipLaunchKernelGGL((sumcheck_round_kernel<FL, K, DEG>), dim3(blocks), dim3(256), lds, ctx->stream, a, fd);
         HIP_TRY(ctx, hipGetLastError());
     }
-    {
+    if (!a.done) {
         LaunchTimer t(ctx, "sumcheck_reduce_kernel");
         hipLaunchKernelGGL(sumcheck_reduce_kernel<FL>, dim3(1), dim3(256), 0, ctx->stream, a.partials, blocks, (uint32_t)(DEG + 1),
-                           s->evals_d, fd);
+                           a.evals_out, fd);
         HIP_TRY(ctx, hipGetLastError());
     }
     return ZIP_OK;
@@ -1048,6 +1081,7 @@ int32_t sumcheck_round_fl(zip_sumcheck *s, const uint64_t *r_prev, const HostFie
     a.half = (uint64_t)1 << (s->num_vars - round);
     a.fold = round > 1;
     a.partials = s->partials;
+    a.evals_out = s->evals_pinned ? reinterpret_cast<uint64_t *>(s->evals_pinned) : s->evals_d;
     a.n_terms = s->n_terms;
     uint64_t minus_one[8] = {0};
     for (int i = 0; i < FL; i++) {
@@ -1070,6 +1104,7 @@ int32_t sumcheck_round_fl(zip_sumcheck *s, const uint64_t *r_prev, const HostFie
         for (int i = 0; i < FL; i++) a.r[i] = r_prev[i];
     uint64_t want = (a.half + 255) / 256;
     uint32_t blocks = (uint32_t)std::min<uint64_t>(want ? want : 1, s->max_blocks);
+    a.done = blocks <= 64 ? s->done_d : nullptr;  // small rounds: one launch, the last workgroup folds the partials
     const FieldDev<FL> fd = to_dev<FL>(hf);
     switch (s->n_mles) {
         case 1: return sumcheck_round_k<FL, 1>(s, a, blocks, fd);
@@ -2084,6 +2119,9 @@ int32_t zip_sumcheck_init(int32_t device, const uint64_t *const *mles, zip_mem_k
         s->max_blocks = (uint32_t)cus * 8;
         if ((rc = pool_alloc(ctx, (size_t)s->max_blocks * (degree + 1) * elem, (void **)&s->partials))) break;
         if ((rc = pool_alloc(ctx, (size_t)(degree + 1) * elem, (void **)&s->evals_d))) break;
+        if ((rc = pool_alloc(ctx, 16, (void **)&s->done_d))) break;
+        if (hipMemsetAsync(s->done_d, 0, 16, ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
+        s->evals_pinned = slab_take(device);  // null (all slots busy): the message goes through evals_d and a copy
     } while (0);
     if (rc) {
         zip_sumcheck_free(s);
@@ -2113,8 +2151,13 @@ int32_t zip_sumcheck_round(zip_sumcheck *s, const uint64_t *r_prev, uint64_t *ev
     }
     if (rc) return rc;
     s->round++;
-    HIP_TRY(ctx, hipMemcpyAsync(evaluations_out, s->evals_d, (size_t)(s->degree + 1) * s->fl * 8, hipMemcpyDeviceToHost,
-                                ctx->stream));
+    const size_t msg_bytes = (size_t)(s->degree + 1) * s->fl * 8;
+    if (s->evals_pinned) {  // the kernel wrote the message into host-mapped memory: complete once the stream is idle
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(evaluations_out, s->evals_pinned, msg_bytes);
+        return ZIP_OK;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(evaluations_out, s->evals_d, msg_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ZIP_OK;
 }
@@ -2124,6 +2167,8 @@ const char *zip_sumcheck_last_error(const zip_sumcheck *s) { return s && s->ctx 
 void zip_sumcheck_free(zip_sumcheck *s) {
     if (!s) return;
     if (s->ctx) {
+        if (s->ctx->stream) (void)hipStreamSynchronize(s->ctx->stream);
+        slab_give(s->ctx->device, s->evals_pinned);
         if (!s->owned) {  // the caller's tables are not ours to free
             std::lock_guard<std::mutex> g(s->ctx->mu);
             for (auto *p : s->input) s->ctx->live_blocks.erase(const_cast<uint64_t *>(p));
