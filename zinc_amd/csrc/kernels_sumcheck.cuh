@@ -61,6 +61,8 @@ struct SumcheckRoundArgs {
     uint32_t *done;                         // arrival counter (zero between launches): the last workgroup folds the
                                             // partials; nullptr = sumcheck_reduce_kernel does it in a second launch
     uint64_t *evals_out;                    // [degree + 1][FL], device memory or host-mapped pinned memory
+    uint32_t *host_flag;                    // host-mapped word set to `seq` after the message (the host polls it), or null
+    uint32_t seq;
     // combination function: n_terms == 0: the product of all MLE values; otherwise
     //   (sum_t coeff[t] * prod_{j in term_mask[t]} vals[j]) * vals[K - 1]   (zinc/utils.rs:77-94)
     uint32_t n_terms;
@@ -236,13 +238,20 @@ __global__ void __launch_bounds__(256) sumcheck_round_kernel(SumcheckRoundArgs<F
         }
         if (tid < FL) a.evals_out[(size_t)e * FL + tid] = red[tid];
     }
-    if (tid == 0) *a.done = 0;  // the next round's launch is ordered after this one on the stream
+    if (tid == 0) {
+        *a.done = 0;  // the next round's launch is ordered after this one on the stream
+        if (a.host_flag) {  // the message was stored by this wave (tid < FL): order it before the flag, system-wide
+            __threadfence_system();
+            __hip_atomic_store(a.host_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // evaluations[e] = sum over the blocks' partials (one workgroup; blocks <= a few thousand)
 template <int FL>
 __global__ void __launch_bounds__(256) sumcheck_reduce_kernel(const uint64_t *partials, uint32_t blocks, uint32_t ne,
-                                                              uint64_t *evaluations, FieldDev<FL> f) {
+                                                              uint64_t *evaluations, FieldDev<FL> f,
+                                                              uint32_t *host_flag = nullptr, uint32_t seq = 0) {
     __shared__ uint64_t red[256 * FL];
     const uint32_t tid = threadIdx.x;
     for (uint32_t e = 0; e < ne; e++) {
@@ -268,6 +277,10 @@ __global__ void __launch_bounds__(256) sumcheck_reduce_kernel(const uint64_t *pa
         }
         if (tid < FL) evaluations[(size_t)e * FL + tid] = red[tid];
         __syncthreads();
+    }
+    if (host_flag && tid == 0) {  // as in sumcheck_round_kernel
+        __threadfence_system();
+        __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

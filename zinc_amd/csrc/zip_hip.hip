@@ -5,6 +5,7 @@
 // HIP-event measurement hooks used by bench.py.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <thread>
 
@@ -117,6 +118,7 @@ struct zip_sumcheck {
     unsigned char *evals_pinned = nullptr;  // host-mapped slot the round message is written to (or null: evals_d + a copy)
     uint32_t max_blocks = 0;
     uint64_t modulus[8] = {};
+    uint64_t mont_r[8] = {}, mont_r2[8] = {}, mont_inv = 0;  // Montgomery constants, computed once (512 modular doublings)
     uint32_t n_terms = 0, term_mask[8] = {};  // zip_sumcheck_comb, or n_terms == 0 for the plain product
     uint64_t coeff[8][8] = {};
 };
@@ -223,7 +225,7 @@ unsigned char *slab_take(int device) {
     if (device < 0 || device >= kMaxDevices) return nullptr;
     PinnedSlab &sl = g_slab[device];
     std::lock_guard<std::mutex> g(sl.mu);
-    if (!sl.base && hipHostMalloc((void **)&sl.base, (size_t)kSlabSlots * kSlabSlotBytes, hipHostMallocDefault) != hipSuccess) {
+    if (!sl.base && hipHostMalloc((void **)&sl.base, (size_t)kSlabSlots * kSlabSlotBytes, hipHostMallocCoherent) != hipSuccess) {
         sl.base = nullptr;
         return nullptr;
     }
@@ -1057,7 +1059,7 @@ int32_t launch_sumcheck_round(zip_sumcheck *s, const SumcheckRoundArgs<FL> &a, u
     if (!a.done) {
         LaunchTimer t(ctx, "sumcheck_reduce_kernel");
         hipLaunchKernelGGL(sumcheck_reduce_kernel<FL>, dim3(1), dim3(256), 0, ctx->stream, a.partials, blocks, (uint32_t)(DEG + 1),
-                           a.evals_out, fd);
+                           a.evals_out, fd, a.host_flag, a.seq);
         HIP_TRY(ctx, hipGetLastError());
     }
     return ZIP_OK;
@@ -1082,6 +1084,8 @@ int32_t sumcheck_round_fl(zip_sumcheck *s, const uint64_t *r_prev, const HostFie
     a.fold = round > 1;
     a.partials = s->partials;
     a.evals_out = s->evals_pinned ? reinterpret_cast<uint64_t *>(s->evals_pinned) : s->evals_d;
+    a.host_flag = s->evals_pinned ? reinterpret_cast<uint32_t *>(s->evals_pinned + 192) : nullptr;
+    a.seq = round;
     a.n_terms = s->n_terms;
     uint64_t minus_one[8] = {0};
     for (int i = 0; i < FL; i++) {
@@ -2088,6 +2092,9 @@ int32_t zip_sumcheck_init(int32_t device, const uint64_t *const *mles, zip_mem_k
         s->degree = degree;
         s->fl = hf.fl;
         memcpy(s->modulus, hf.modulus, sizeof s->modulus);
+        memcpy(s->mont_r, hf.r, sizeof s->mont_r);
+        memcpy(s->mont_r2, hf.r2, sizeof s->mont_r2);
+        s->mont_inv = hf.inv;
         if (comb) {
             s->n_terms = comb->n_terms;
             for (uint32_t t = 0; t < comb->n_terms; t++) {
@@ -2122,6 +2129,7 @@ int32_t zip_sumcheck_init(int32_t device, const uint64_t *const *mles, zip_mem_k
         if ((rc = pool_alloc(ctx, 16, (void **)&s->done_d))) break;
         if (hipMemsetAsync(s->done_d, 0, 16, ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
         s->evals_pinned = slab_take(device);  // null (all slots busy): the message goes through evals_d and a copy
+        if (s->evals_pinned) memset(s->evals_pinned, 0, kSlabSlotBytes);
     } while (0);
     if (rc) {
         zip_sumcheck_free(s);
@@ -2139,11 +2147,12 @@ int32_t zip_sumcheck_round(zip_sumcheck *s, const uint64_t *r_prev, uint64_t *ev
     if (s->round == 0 && r_prev) return fail(ctx, ZIP_ERR_INVALID_PARAM, "first round should be prover first.");
     if (s->round > 0 && !r_prev) return fail(ctx, ZIP_ERR_INVALID_PARAM, "verifier message is empty");
     HostField hf;
-    zip_field zf{};
-    zf.limbs = s->fl;
-    memcpy(zf.modulus, s->modulus, sizeof zf.modulus);
+    hf.fl = s->fl;
+    memcpy(hf.modulus, s->modulus, sizeof hf.modulus);
+    memcpy(hf.r, s->mont_r, sizeof hf.r);
+    memcpy(hf.r2, s->mont_r2, sizeof hf.r2);
+    hf.inv = s->mont_inv;
     int32_t rc;
-    if ((rc = make_field(ctx, &zf, &hf))) return rc;
     switch (s->fl) {
         case 2: rc = sumcheck_round_fl<2>(s, r_prev, hf); break;
         case 3: rc = sumcheck_round_fl<3>(s, r_prev, hf); break;
@@ -2152,8 +2161,18 @@ int32_t zip_sumcheck_round(zip_sumcheck *s, const uint64_t *r_prev, uint64_t *ev
     if (rc) return rc;
     s->round++;
     const size_t msg_bytes = (size_t)(s->degree + 1) * s->fl * 8;
-    if (s->evals_pinned) {  // the kernel wrote the message into host-mapped memory: complete once the stream is idle
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (s->evals_pinned) {
+        // The kernel writes the message, then the round number, into host-mapped coherent memory: poll that word
+        // for a while (a stream synchronise costs ~20 us of wake-up latency, forty times per proof), then fall back.
+        volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(s->evals_pinned + 192);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (uint32_t spin = 0;; spin++) {
+            if (*flag == s->round) { seen = true; break; }
+            if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+        }
+        if (seen) std::atomic_thread_fence(std::memory_order_acquire);
+        else HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         memcpy(evaluations_out, s->evals_pinned, msg_bytes);
         return ZIP_OK;
     }
