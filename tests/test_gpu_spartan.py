@@ -388,3 +388,34 @@ def test_one_prepared_circuit_shared_by_concurrent_provers(mods):
         want = orc.Ccs(_ccs.vitalik_ccs(x)).spartan_prove(f, orc.new_transcript())
         for key in ("msgs1", "msgs2", "V_s", "r_y"):
             assert np.array_equal(out[x][key], want[key]), (x, key)
+
+
+def test_prover_rejects_what_the_reference_prover_cannot_handle(mods):
+    """Shapes on which the reference's own prover panics or silently mis-indexes are refused, not computed."""
+    _, pcs = mods
+    field = pcs.FieldConfig(Q192, 3)
+    inst = _ccs.dummy_ccs_from_len(8)
+    prover = pcs.ZincProver()
+    x, w = inst.z[:1], inst.z[2:]
+
+    def run(**kw):
+        a = dict(matrices=inst.matrices, s=inst.s, d=inst.d, S=inst.S, c=inst.c, public_input=x, w_ccs=w)
+        a.update(kw)
+        return prover.spartan_prove(a["matrices"], a["s"], a["d"], a["S"], a["c"], a["public_input"], a["w_ccs"],
+                                    pcs.KeccakTranscript(), field)
+
+    run()  # the honest call works
+    with pytest.raises(pcs.InvalidPcsParam):  # a zero coefficient shifts the MLE list comb_fn_1 indexes (zinc/utils.rs:66-88)
+        run(c=[1, 0])
+    run(S=[[1, 0], [2]])  # the same multiset: fine
+    with pytest.raises(pcs.InvalidPcsParam):  # S must enumerate the matrices in order: comb_fn_1 reads vals[j] by matrix number
+        run(S=[[2], [0, 1]])
+    with pytest.raises(pcs.ReferencePanic):   # z longer than the matrices are wide: LengthsNotEqual (ccs/utils.rs:52-59)
+        run(w_ccs=np.zeros(20, dtype=np.int64))
+    with pytest.raises(pcs.ReferencePanic):   # n_cols != 2^s
+        run(s=2)
+    wide = _ccs.CsrMatrix(8, 8, [[(1, 9)]])   # a column index outside the matrix: the reference indexes out of bounds
+    with pytest.raises(pcs.ReferencePanic):
+        run(matrices=[wide, inst.matrices[1], inst.matrices[2]])
+    with pytest.raises(pcs.InvalidPcsParam):  # degree above what the round kernel is instantiated for
+        run(d=6)
