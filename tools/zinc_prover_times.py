@@ -48,7 +48,7 @@ prep = C.c_void_p()
 assert L.zinc_prover_prepare(arr, inst.t, s, field._m.ctypes.data, fl, 0, C.byref(prep)) == 0, L.zinc_last_error()
 
 
-def run(with_pcs, prepared=None):
+def run(with_pcs, prepared=None, keep=None):
     """the C facade only: what a Rust caller pays (CSR + z in host memory, proof kept in the returned handle)"""
     t = pcs.KeccakTranscript()
     h = C.c_void_p()
@@ -61,17 +61,37 @@ def run(with_pcs, prepared=None):
     n = 0
     if with_pcs:
         n = L.zinc_zip_proof_len(h)
+        if keep is not None:  # hand the ZipProof out for the verifier timing
+            keep["roots"] = np.zeros((L.zinc_zip_proof_num_roots(h), 32), np.uint8)
+            keep["v"] = np.zeros(fl, np.uint64)
+            keep["proof"] = np.zeros(n, np.uint8)
+            L.zinc_zip_proof_read(h, keep["roots"].ctypes.data, keep["v"].ctypes.data, keep["proof"].ctypes.data)
         L.zinc_zip_proof_free(h)
     return dt, n
+
+
+def verify(zp, prepared):
+    """Verifier::verify through the facade (proof bytes in host memory)"""
+    t = pcs.KeccakTranscript()
+    t0 = time.perf_counter()
+    rc = L.zinc_verifier_verify(arr, inst.t, s, d, inst.q, masks.ctypes.data, cv.ctypes.data, t._h, field._m.ctypes.data, fl, 0,
+                                prepared, sp["msgs1"].ctypes.data, sp["msgs2"].ctypes.data, sp["V_s"].ctypes.data, 1,
+                                zp["roots"].ctypes.data, zp["roots"].shape[0], zp["v"].ctypes.data, zp["proof"].ctypes.data,
+                                zp["proof"].size, None, None, None)
+    dt = time.perf_counter() - t0
+    assert rc == 0, L.zinc_last_error()
+    return dt
 
 
 for rep in range(args.reps):
     ts, _ = run(0)
     tf, n = run(1)
     tsp, _ = run(0, prep)
-    tfp, _ = run(1, prep)
+    zp = {}
+    tfp, _ = run(1, prep, zp)
+    tv = verify(zp, prep) if args.prime != "256" else float("nan")  # (the reference rejects its own PCS proofs for that modulus)
     print(f"2^{args.nv} ({args.prime}): SpartanProver::prove {1e3 * ts:8.2f} ms   Prover::prove {1e3 * tf:8.2f} ms "
-          f"(PCS proof {n / 2**20:.0f} MiB);  with the circuit prepared: {1e3 * tsp:8.2f} / {1e3 * tfp:8.2f} ms", flush=True)
+          f"(PCS proof {n / 2**20:.0f} MiB);  with the circuit prepared: {1e3 * tsp:8.2f} / {1e3 * tfp:8.2f} ms; Verifier::verify {1e3 * tv:7.2f} ms", flush=True)
 
 L.zinc_prepared_ccs_free(prep)
 if args.oracle:

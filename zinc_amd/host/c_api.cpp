@@ -449,12 +449,11 @@ int32_t zinc_verifier_verify(const zip_sparse_matrix *constraints, uint32_t t, u
         st.constraints.resize(t);
         std::unique_ptr<zinc::PreparedCcs> own;
         if (!prepared) own = std::make_unique<zinc::PreparedCcs>(constraints, t, s, f, device);
-        zinc::zip::ZipProof zp;
-        zp.z_comm.roots.resize(n_roots);
-        std::memcpy(zp.z_comm.roots.data(), roots, n_roots * 32);
-        zp.v = load(v, limbs);
-        zp.pcs_proof.assign(pcs_proof, pcs_proof + pcs_proof_len);
-        verifier.verify_pcs_proof(st, zp, pts, ccs, transcript->t, f, prepared ? prepared->p.get() : own.get());
+        zinc::zip::MultilinearZipCommitment z_comm;
+        z_comm.roots.resize(n_roots);
+        std::memcpy(z_comm.roots.data(), roots, n_roots * 32);
+        verifier.verify_pcs_proof(st, z_comm, load(v, limbs), pcs_proof, pcs_proof_len, pts, ccs, transcript->t, f,
+                                  prepared ? prepared->p.get() : own.get());  // the proof bytes are read in place
     });
 }
 

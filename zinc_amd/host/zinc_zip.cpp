@@ -739,10 +739,10 @@ void MultilinearZip::verify(const MultilinearZipParams &vp, const MultilinearZip
     point_to_tensor(field, num_rows, point, point_len, q0, q1);
     const zip_field zf = field.to_abi();
     const size_t len = zip_proof_len(ctx, (uint32_t)cols.size(), field.limbs);
-    const size_t avail = transcript.stream.size() - transcript.read_pos;
+    const size_t avail = transcript.read_size() - transcript.read_pos;
     zip_verify_report rep{};
     check(ctx,
-          zip_verify(ctx, comm.roots.empty() ? nullptr : comm.roots[0].data(), transcript.stream.data() + transcript.read_pos,
+          zip_verify(ctx, comm.roots.empty() ? nullptr : comm.roots[0].data(), transcript.read_data() + transcript.read_pos,
                      ZIP_MEM_HOST, avail, coeffs.empty() ? nullptr : coeffs.data(), cols.data(), (uint32_t)cols.size(),
                      q0.empty() ? nullptr : q0.data(), q1.empty() ? nullptr : q1.data(), eval.data(), &zf, &rep),
           "zip_verify");
@@ -756,7 +756,7 @@ void MultilinearZip::verify(const MultilinearZipParams &vp, const MultilinearZip
         default: throw ZipError(ZipError::Transcript, "Failed to read the proof stream");
     }
     // read_field_elements absorbed every element of the evaluation row (pcs_transcript.rs:138-160)
-    const uint8_t *row_be = transcript.stream.data() + transcript.read_pos + len - (size_t)row_len * field.limbs * 8;
+    const uint8_t *row_be = transcript.read_data() + transcript.read_pos + len - (size_t)row_len * field.limbs * 8;
     for (uint32_t c = 0; c < row_len; c++) {
         Limbs v{};
         const uint8_t *b = row_be + (size_t)c * field.limbs * 8;
@@ -1188,16 +1188,17 @@ VerificationPoints ZincVerifier::spartan_verify(const SpartanProof &proof, const
     return out;
 }
 
-void ZincVerifier::verify_pcs_proof(const ccs::Statement_Z &statement, const zip::ZipProof &zip_proof,
+void ZincVerifier::verify_pcs_proof(const ccs::Statement_Z &statement, const zip::MultilinearZipCommitment &z_comm,
+                                    const Limbs &v, const uint8_t *pcs_proof, size_t pcs_proof_len,
                                     const VerificationPoints &points, const ccs::CCS_Z &ccs, KeccakTranscript &transcript,
                                     const FieldConfig &config, PreparedCcs *prepared) const {
     if (points.rx_ry.size() != ccs.s + ccs.s_prime) throw std::logic_error("range end index out of range for rx_ry");
     zip::KeccakSeedSource seeds(transcript);
     const zip::RaaCode linear_code = zip::RaaCode::make(lc_spec_, ccs.m, seeds);                  // :234
     const zip::MultilinearZipParams param = zip::MultilinearZip::setup(ccs.m, linear_code, device_);  // :235
-    zip::PcsTranscript pcs_transcript = zip::PcsTranscript::from_proof(zip_proof.pcs_proof.data(), zip_proof.pcs_proof.size());
+    zip::PcsTranscript pcs_transcript = zip::PcsTranscript::from_proof_view(pcs_proof, pcs_proof_len);  // :236
     const Limbs *r_y = points.rx_ry.data() + ccs.s;
-    zip::MultilinearZip::verify(param, zip_proof.z_comm, r_y, ccs.s_prime, zip_proof.v, pcs_transcript, config);  // :239-246
+    zip::MultilinearZip::verify(param, z_comm, r_y, ccs.s_prime, v, pcs_transcript, config);  // :239-246
     // V_xy (:248-261) on the device
     std::unique_ptr<PreparedCcs> own;
     if (!prepared) {
@@ -1215,7 +1216,7 @@ void ZincVerifier::verify_pcs_proof(const ccs::Statement_Z &statement, const zip
     for (size_t k = 0; k < ccs.t; k++)
         for (uint32_t i = 0; i < config.limbs; i++) V_xy[k][i] = vxy[k * config.limbs + i];
     Limbs lhs = lin_comb_V_s(config, points.gamma, V_xy);  // :264
-    config.mul_assign(lhs, zip_proof.v);
+    config.mul_assign(lhs, v);
     if (lhs != points.e_y)
         throw SpartanError(SpartanError::PcsVerification, "linear combination of powers of gamma and V_x != e_y");
 }

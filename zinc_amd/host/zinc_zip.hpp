@@ -176,11 +176,23 @@ struct PcsTranscript {
     ByteStream stream;
     size_t read_pos = 0;  // Cursor position of the reading side (PcsTranscript::from_proof, :28-35)
 
+    const uint8_t *borrowed = nullptr;  // reading side over the caller's bytes (from_proof_view): nothing is copied
+    size_t borrowed_len = 0;
+
     static PcsTranscript from_proof(const uint8_t *proof, size_t len) {
         PcsTranscript t;
         t.stream.assign(proof, proof + len);
         return t;
     }
+    // the same without taking a copy of a proof that may be GiBs; the bytes must outlive the transcript
+    static PcsTranscript from_proof_view(const uint8_t *proof, size_t len) {
+        PcsTranscript t;
+        t.borrowed = proof;
+        t.borrowed_len = len;
+        return t;
+    }
+    const uint8_t *read_data() const { return borrowed ? borrowed : stream.data(); }
+    size_t read_size() const { return borrowed ? borrowed_len : stream.size(); }
 
     void write_field_elements(const FieldConfig &f, const Limbs *elems, size_t n);  // :76-113
     void append(const uint8_t *bytes, size_t n) { stream.insert(stream.end(), bytes, bytes + n); }
@@ -401,6 +413,14 @@ class ZincVerifier {
                                       const FieldConfig &config) const;
     // verify_pcs_proof (:221-273)
     void verify_pcs_proof(const ccs::Statement_Z &statement, const zip::ZipProof &zip_proof, const VerificationPoints &points,
+                          const ccs::CCS_Z &ccs, KeccakTranscript &transcript, const FieldConfig &config,
+                          PreparedCcs *prepared = nullptr) const {
+        verify_pcs_proof(statement, zip_proof.z_comm, zip_proof.v, zip_proof.pcs_proof.data(), zip_proof.pcs_proof.size(), points,
+                         ccs, transcript, config, prepared);
+    }
+    // the same over borrowed proof bytes
+    void verify_pcs_proof(const ccs::Statement_Z &statement, const zip::MultilinearZipCommitment &z_comm, const Limbs &v,
+                          const uint8_t *pcs_proof, size_t pcs_proof_len, const VerificationPoints &points,
                           const ccs::CCS_Z &ccs, KeccakTranscript &transcript, const FieldConfig &config,
                           PreparedCcs *prepared = nullptr) const;
 
