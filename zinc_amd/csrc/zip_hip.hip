@@ -413,8 +413,9 @@ void parallel_memcpy(void *dst, const void *src, size_t bytes) {
         memcpy(dst, src, bytes);
         return;
     }
+    static const unsigned n_env = getenv("ZIP_HIP_COPY_THREADS") ? (unsigned)atoi(getenv("ZIP_HIP_COPY_THREADS")) : 0u;
     unsigned n = std::thread::hardware_concurrency();
-    n = n ? std::min(n, 8u) : 4u;
+    n = n_env ? std::min(n_env, 64u) : n ? std::min(n, 8u) : 4u;
     const size_t per = (((bytes + n - 1) / n) + 4095) & ~(size_t)4095;  // n * per >= bytes (a truncating bytes / n lost a tail of < n bytes)
     std::vector<std::thread> th;
     for (unsigned t = 1; t < n; t++) {
