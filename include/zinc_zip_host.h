@@ -135,6 +135,14 @@ int32_t zinc_sumcheck_prove_ccs(zinc_transcript *transcript, const uint64_t *con
                                 const uint32_t *s_masks, const uint64_t *modulus, uint32_t limbs, int32_t device,
                                 uint64_t *msgs_out, uint64_t *randomness_out);
 
+/* MLSumcheck::prove_as_subprotocol with rand_poly_comb_fn (src/sumcheck/utils.rs:67-78), the workload of
+ * benches/sumcheck_benches.rs: sum_p coeffs[p] * prod_{j in masks[p]} vals[j] (bit j of masks[p]: MLE j is a factor;
+ * 1..4 factors per product, up to 32 MLEs).  coeffs: n_products field elements (Montgomery). */
+int32_t zinc_sumcheck_prove_products(zinc_transcript *transcript, const uint64_t *const *mles, uint32_t n_mles,
+                                     uint32_t nvars, uint32_t degree, uint32_t n_products, const uint64_t *coeffs,
+                                     const uint32_t *masks, const uint64_t *modulus, uint32_t limbs, int32_t device,
+                                     uint64_t *msgs_out, uint64_t *randomness_out);
+
 /* ZincProver (src/zinc/prover.rs): Prover::prove (:50-88) when with_pcs != 0, else
  * prepare_for_random_field_piop + SpartanProver::prove (:130-161, what benches/spartan_benches.rs times).
  *   constraints   Statement_Z.constraints as CSR (zip_sparse_matrix, include/zip_hip.h), t matrices of

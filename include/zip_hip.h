@@ -230,6 +230,11 @@ int32_t zip_sumcheck_init(int32_t device, const uint64_t *const *mles, zip_mem_k
                           uint32_t num_vars, uint32_t degree, const zip_sumcheck_comb *comb, const zip_field *field,
                           zip_sumcheck **out);
 int32_t zip_sumcheck_round(zip_sumcheck *s, const uint64_t *r_prev, uint64_t *evaluations_out);
+/* The same round in two halves -- enqueue, then collect -- so that several handles (the products of a
+ * sum-of-products polynomial, src/sumcheck/utils.rs:27-78: each product folds its own MLEs, the round messages
+ * add up) work at the same time on their own streams. */
+int32_t zip_sumcheck_round_begin(zip_sumcheck *s, const uint64_t *r_prev);
+int32_t zip_sumcheck_round_end(zip_sumcheck *s, uint64_t *evaluations_out);
 const char *zip_sumcheck_last_error(const zip_sumcheck *s);
 void zip_sumcheck_free(zip_sumcheck *s);
 

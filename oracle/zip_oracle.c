@@ -1214,8 +1214,9 @@ void orc_mle_eval_field(const orc_field *f, const uint64_t *evals, uint32_t eval
 /* ------------------------------------------------------------------ sumcheck prover */
 /* comb_fn over the values of the MLEs at one point: the product of all of them (n_terms == 0,
  * zinc/prover.rs:300) or sumcheck_polynomial_comb_fn_1 (zinc/utils.rs:77-94) */
+#define SC_MAX_MLES 32
 static void sc_comb(const orc_field *f, uint64_t (*vals)[ORC_MAX_FL], uint32_t n_mles, uint32_t n_terms,
-                    const uint32_t *term_masks, const uint64_t *coeffs, uint64_t *out) {
+                    const uint32_t *term_masks, const uint64_t *coeffs, int times_last, uint64_t *out) {
     const uint32_t fl = f->fl;
     if (n_terms == 0) {
         memcpy(out, vals[0], 8 * fl);
@@ -1229,15 +1230,15 @@ static void sc_comb(const orc_field *f, uint64_t (*vals)[ORC_MAX_FL], uint32_t n
             if ((term_masks[t] >> j) & 1u) orc_field_mul(f, term, vals[j]);
         orc_field_add(f, result, term);
     }
-    orc_field_mul(f, result, vals[n_mles - 1]); /* eq() is the last MLE */
+    if (times_last) orc_field_mul(f, result, vals[n_mles - 1]); /* eq() is the last MLE */
     memcpy(out, result, 8 * fl);
 }
 
-int orc_sumcheck_prove(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint32_t nvars, uint32_t degree,
-                       uint32_t n_terms, const uint32_t *term_masks, const uint64_t *coeffs, orc_keccak *tr,
-                       uint64_t *msgs_out, uint64_t *randomness_out) {
+static int sc_prove(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint32_t nvars, uint32_t degree,
+                    uint32_t n_terms, const uint32_t *term_masks, const uint64_t *coeffs, int times_last, orc_keccak *tr,
+                    uint64_t *msgs_out, uint64_t *randomness_out) {
     const uint32_t fl = f->fl;
-    if (nvars == 0 || n_mles == 0 || n_mles > 8 || degree > 8) return ORC_ERR_PARAM;
+    if (nvars == 0 || n_mles == 0 || n_mles > SC_MAX_MLES || degree > 8) return ORC_ERR_PARAM;
     const size_t n = (size_t)1 << nvars;
     uint64_t t[ORC_MAX_FL];
     /* sumcheck.rs:64-76: nvars and degree enter the transcript as field elements (u128 map) */
@@ -1266,10 +1267,10 @@ int orc_sumcheck_prove(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint
         uint64_t evals[9][ORC_MAX_FL];
         memset(evals, 0, sizeof evals);
         for (size_t b = 0; b < half; b++) {
-            uint64_t v0[8][ORC_MAX_FL], vals[8][ORC_MAX_FL], step[8][ORC_MAX_FL], c[ORC_MAX_FL];
+            uint64_t v0[SC_MAX_MLES][ORC_MAX_FL], vals[SC_MAX_MLES][ORC_MAX_FL], step[SC_MAX_MLES][ORC_MAX_FL], c[ORC_MAX_FL];
             for (uint32_t k = 0; k < n_mles; k++)
                 memcpy(v0[k], mles + ((size_t)k * n + 2 * b) * fl, 8 * fl);
-            sc_comb(f, v0, n_mles, n_terms, term_masks, coeffs, c);
+            sc_comb(f, v0, n_mles, n_terms, term_masks, coeffs, times_last, c);
             orc_field_add(f, evals[0], c);
             if (degree > 0) {
                 for (uint32_t k = 0; k < n_mles; k++) {
@@ -1277,11 +1278,11 @@ int orc_sumcheck_prove(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint
                     memcpy(step[k], vals[k], 8 * fl);
                     orc_field_sub(f, step[k], v0[k]);
                 }
-                sc_comb(f, vals, n_mles, n_terms, term_masks, coeffs, c);
+                sc_comb(f, vals, n_mles, n_terms, term_masks, coeffs, times_last, c);
                 orc_field_add(f, evals[1], c);
                 for (uint32_t e = 2; e <= degree; e++) {
                     for (uint32_t k = 0; k < n_mles; k++) orc_field_add(f, vals[k], step[k]);
-                    sc_comb(f, vals, n_mles, n_terms, term_masks, coeffs, c);
+                    sc_comb(f, vals, n_mles, n_terms, term_masks, coeffs, times_last, c);
                     orc_field_add(f, evals[e], c);
                 }
             }
@@ -1296,6 +1297,21 @@ int orc_sumcheck_prove(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint
         orc_tr_absorb_field(tr, f, r);   /* sumcheck.rs:103 */
     }
     return ORC_OK;
+}
+
+int orc_sumcheck_prove(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint32_t nvars, uint32_t degree,
+                       uint32_t n_terms, const uint32_t *term_masks, const uint64_t *coeffs, orc_keccak *tr,
+                       uint64_t *msgs_out, uint64_t *randomness_out) {
+    return sc_prove(f, mles, n_mles, nvars, degree, n_terms, term_masks, coeffs, 1, tr, msgs_out, randomness_out);
+}
+
+/* comb(vals) = sum_p coeffs[p] * prod_{j in masks[p]} vals[j]: rand_poly_comb_fn (src/sumcheck/utils.rs:67-78), the
+ * combination function of benches/sumcheck_benches.rs and src/sumcheck/tests.rs; up to 32 MLEs */
+int orc_sumcheck_prove_products(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint32_t nvars, uint32_t degree,
+                                uint32_t n_products, const uint32_t *masks, const uint64_t *coeffs, orc_keccak *tr,
+                                uint64_t *msgs_out, uint64_t *randomness_out) {
+    if (n_products == 0) return ORC_ERR_PARAM;
+    return sc_prove(f, mles, n_mles, nvars, degree, n_products, masks, coeffs, 0, tr, msgs_out, randomness_out);
 }
 
 int orc_sumcheck_prove_product(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint32_t nvars,

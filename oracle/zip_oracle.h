@@ -238,6 +238,12 @@ int orc_ccs_eval_matrices(const orc_field *f, const orc_ccs *ccs, const uint64_t
 int orc_spartan_final_check(const orc_field *f, const orc_ccs *ccs, const uint64_t *r_x, const uint64_t *r_y,
                             const uint64_t *gamma, const uint64_t *v, const uint64_t *e_y);
 
+/* MLSumcheck::prove_as_subprotocol with rand_poly_comb_fn (src/sumcheck/utils.rs:67-78): sum_p coeffs[p] * prod_{j in
+ * masks[p]} vals[j] -- the workload of benches/sumcheck_benches.rs (rand_poly: 7 products of 2-4 fresh MLEs) */
+int orc_sumcheck_prove_products(const orc_field *f, uint64_t *mles, uint32_t n_mles, uint32_t nvars, uint32_t degree,
+                                uint32_t n_products, const uint32_t *masks, const uint64_t *coeffs, orc_keccak *tr,
+                                uint64_t *msgs_out, uint64_t *randomness_out);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

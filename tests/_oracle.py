@@ -309,6 +309,21 @@ def sumcheck_verify(f: Field, nvars, degree, claimed_mont: int, msgs: np.ndarray
     return rc, point[:nvars], limbs_to_int(exp[: f.fl])
 
 
+def sumcheck_prove_products(f: Field, mles: np.ndarray, degree: int, masks, coeffs_mont, transcript: Keccak):
+    """prove_as_subprotocol with rand_poly_comb_fn (sumcheck/utils.rs:67-78): sum_p coeffs[p] * prod_{j in masks[p]} vals[j]."""
+    m = np.ascontiguousarray(mles, dtype=np.uint64).copy()
+    K, n, fl = m.shape
+    nv = n.bit_length() - 1
+    msgs = np.zeros((nv, degree + 1, fl), dtype=np.uint64)
+    rand = np.zeros((nv, fl), dtype=np.uint64)
+    mk = np.ascontiguousarray(masks, dtype=np.uint32)
+    cf = field_elems(list(coeffs_mont), fl)
+    rc = lib().orc_sumcheck_prove_products(C.byref(f), _u64p(m), K, nv, degree, mk.size, _u32p(mk), _u64p(cf),
+                                           C.byref(transcript), _u64p(msgs), _u64p(rand))
+    assert rc == 0, rc
+    return msgs, rand
+
+
 def build_eq_x_r(f: Field, r: np.ndarray) -> np.ndarray:
     nvars = r.shape[0]
     out = np.zeros((1 << nvars, f.fl), dtype=np.uint64)

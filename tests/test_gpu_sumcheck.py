@@ -146,3 +146,51 @@ def test_sumcheck_ccs_general_terms_and_zero_coefficients(mods):
         r = rand_o[i]
     with pytest.raises(cabi.ZipError):
         cabi.Sumcheck(dev, nv, 4, cabi.make_field(modulus, fl), comb=cabi.make_comb([0b10000], orc.field_elems([c[0]], fl)))
+
+
+# ------------------------------------------------------------------ sum of products (benches/sumcheck_benches.rs)
+def _rand_poly_tables(modulus, fl, nv, products, seed):
+    """rand_poly (sumcheck/utils.rs:27-65) with our own PRNG: fresh MLEs per product, a random coefficient each.
+    Canonical residues as Montgomery limbs: the limbs below the modulus' top limb random, that one below 2^62."""
+    rng = np.random.default_rng(seed)
+    top = (modulus.bit_length() - 1) // 64  # index of the modulus' highest non-zero limb
+    assert (modulus >> (64 * top)) > (1 << 62)
+
+    def residues(shape):
+        a = np.zeros(shape + (fl,), dtype=np.uint64)
+        a[..., :top] = rng.integers(0, 2**64, size=shape + (top,), dtype=np.uint64)
+        a[..., top] = rng.integers(0, 2**62, size=shape, dtype=np.uint64)
+        return a
+
+    K = sum(products)
+    tables = residues((K, 1 << nv))
+    masks, k = [], 0
+    for m in products:
+        masks.append(sum(1 << (k + i) for i in range(m)))
+        k += m
+    return tables, np.array(masks, dtype=np.uint32), residues((len(products),))
+
+
+@pytest.mark.parametrize("modulus,fl", [(312829638388039969874974628075306023441, 3), (BENCH_MODULUS, 4)])
+@pytest.mark.parametrize("nv,products", [(1, (2,)), (3, (1, 2)), (6, (2, 3, 4)), (10, (2, 3, 4, 2, 3, 4, 2)), (9, (4, 4, 4, 4, 4, 4, 4))])
+def test_sum_of_products_equals_the_oracle(mods, modulus, fl, nv, products):
+    """MLSumcheck::prove_as_subprotocol with rand_poly_comb_fn: every round message and challenge."""
+    _, pcs = mods
+    f = orc.make_field(modulus, fl)
+    tables, masks, coeffs = _rand_poly_tables(modulus, fl, nv, products, seed=nv)
+    degree = max(products)
+    want_msgs, want_rand = orc.sumcheck_prove_products(f, tables, degree, masks, [orc.limbs_to_int(c) for c in coeffs],
+                                                       orc.new_transcript())
+    msgs, rand = pcs.sumcheck_prove_products(pcs.KeccakTranscript(), tables, degree, masks, coeffs, pcs.FieldConfig(modulus, fl))
+    assert np.array_equal(msgs, want_msgs) and np.array_equal(rand, want_rand)
+
+
+def test_sum_of_products_bad_shapes(mods):
+    _, pcs = mods
+    field = pcs.FieldConfig(BENCH_MODULUS, 4)
+    tables, masks, coeffs = _rand_poly_tables(BENCH_MODULUS, 4, 3, (2, 2), seed=1)
+    with pytest.raises(pcs.InvalidPcsParam):  # five multiplicands in one product
+        big, _, c1 = _rand_poly_tables(BENCH_MODULUS, 4, 3, (5,), seed=2)
+        pcs.sumcheck_prove_products(pcs.KeccakTranscript(), big, 5, np.array([31], dtype=np.uint32), c1, field)
+    with pytest.raises(pcs.ReferencePanic):   # a product refers to an MLE that does not exist
+        pcs.sumcheck_prove_products(pcs.KeccakTranscript(), tables, 2, np.array([3, 1 << 7], dtype=np.uint32), coeffs, field)

@@ -158,3 +158,52 @@ def test_sumcheck_verify_agrees_with_the_prover_transcript():
     assert expected * pow(R, -1, q) % q == a * b % q
     rc, _, _ = orc.sumcheck_verify(f, nv, 2, mont(f, q, claimed + 1), msgs, orc.new_transcript())
     assert rc == orc.ORC_ERR_PROOF
+
+
+def rand_poly(f, q, fl, nv, products, seed):
+    """rand_poly (sumcheck/utils.rs:27-65) with our own PRNG: `products` = multiplicands per product, fresh MLEs each.
+    Returns tables [K, 2^nv, fl] (Montgomery), masks, coefficients (Montgomery ints), the claimed sum (canonical int)."""
+    rng = np.random.default_rng(seed)
+    tables, masks, coeffs, total, k = [], [], [], 0, 0
+    for m in products:
+        vals = [[int(rng.integers(0, 2**62)) * 0x9E3779B97F4A7C15 % q for _ in range(1 << nv)] for _ in range(m)]
+        c = int(rng.integers(1, 2**62)) * 0xD1B54A32D192ED03 % q
+        prod_sum = 0
+        for b in range(1 << nv):
+            t = 1
+            for v in vals:
+                t = t * v[b] % q
+            prod_sum += t
+        total = (total + c * prod_sum) % q
+        tables += [orc.field_elems([mont(f, q, x) for x in v], fl) for v in vals]
+        masks.append(sum(1 << (k + i) for i in range(m)))
+        coeffs.append(mont(f, q, c))
+        k += m
+    return np.stack(tables), np.array(masks, dtype=np.uint32), coeffs, total
+
+
+@pytest.mark.parametrize("q,fl", FIELDS[:2])
+@pytest.mark.parametrize("products", [(2,), (2, 3), (4, 2, 3), (2, 3, 4, 2, 3, 4, 2)])
+def test_sum_of_products_sumcheck(q, fl, products):
+    """The combination function of sumcheck_benches.rs / sumcheck/tests.rs (rand_poly_comb_fn): the verifier accepts
+    the claimed sum computed in Python integers, and its subclaim is sum_p c_p prod_j MLE_j(point)."""
+    f = orc.make_field(q, fl)
+    nv = 4
+    tables, masks, coeffs, total = rand_poly(f, q, fl, nv, products, seed=len(products))
+    degree = max(products)
+    tp, tv = orc.new_transcript(), orc.new_transcript()
+    msgs, rand = orc.sumcheck_prove_products(f, tables, degree, masks, coeffs, tp)
+    rc, point, expected = orc.sumcheck_verify(f, nv, degree, mont(f, q, total), msgs, tv)
+    assert rc == 0 and (point == rand).all()
+    eq = eq_table(q, [to_int(f, q, r) for r in point])
+    at = [sum(to_int(f, q, tables[k, i]) * eq[i] for i in range(1 << nv)) % q for k in range(tables.shape[0])]
+    want = 0
+    for mask, c in zip(masks, coeffs):
+        t = to_int(f, q, orc.int_to_limbs(c, fl))
+        for k in range(tables.shape[0]):
+            if (int(mask) >> k) & 1:
+                t = t * at[k] % q
+        want += t
+    assert to_int(f, q, orc.int_to_limbs(expected, fl)) == want % q
+    rc, _, _ = orc.sumcheck_verify(f, nv, degree, mont(f, q, total + 1), msgs, orc.new_transcript())
+    assert rc == orc.ORC_ERR_PROOF

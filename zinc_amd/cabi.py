@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "zip_commitment_device_ptrs", "zip_commit_download", "zip_commitment_upload", "zip_open_testing",
     "zip_open_columns", "zip_open_eval", "zip_proof_len", "zip_open", "zip_sum_partials", "zip_merkle_trees",
     "zip_ctx_set_profiling", "zip_ctx_profile_read", "zip_verify", "zip_mle_eval", "zip_field_map_int256",
-    "zip_open_stream", "zip_sumcheck_init", "zip_sumcheck_round", "zip_sumcheck_last_error", "zip_sumcheck_free",
+    "zip_open_stream", "zip_sumcheck_init", "zip_sumcheck_round", "zip_sumcheck_round_begin", "zip_sumcheck_round_end", "zip_sumcheck_last_error", "zip_sumcheck_free",
     "zip_ccs_create", "zip_ccs_free", "zip_ccs_last_error", "zip_ccs_set_z", "zip_ccs_eq_table",
     "zip_ccs_second_table", "zip_ccs_table", "zip_ccs_download", "zip_ccs_eval_matrices",
 )
@@ -140,6 +140,8 @@ def lib():
     L.zip_sumcheck_init.argtypes = [C.c_int32, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(SumcheckComb),
                                     C.POINTER(ZipField), C.POINTER(vp)]
     L.zip_sumcheck_round.argtypes = [vp, u64p, u64p]
+    L.zip_sumcheck_round_begin.argtypes = [vp, u64p]
+    L.zip_sumcheck_round_end.argtypes = [vp, u64p]
     L.zip_sumcheck_last_error.argtypes = [vp]
     L.zip_sumcheck_last_error.restype = C.c_char_p
     L.zip_sumcheck_free.argtypes = [vp]

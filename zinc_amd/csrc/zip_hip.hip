@@ -110,6 +110,7 @@ struct zip_commitment {
 struct zip_sumcheck {
     zip_ctx *ctx = nullptr;  // private plumbing context (stream, pool, error text)
     uint32_t n_mles = 0, num_vars = 0, degree = 0, fl = 0, round = 0;
+    bool pending = false;  // a round has been enqueued (zip_sumcheck_round_begin) and not yet collected
     const uint64_t *input[4] = {};  // the tables of round 1 (device; owned when `owned`)
     bool owned = false;
     uint64_t *buf[2][4] = {};       // ping-pong fold targets: 2^(nv-1) and 2^(nv-2) entries
@@ -406,6 +407,29 @@ int32_t ensure_bounce(zip_ctx *ctx, size_t bytes) {
     }
     ctx->bounce_cap = bytes;
     return ZIP_OK;
+}
+
+// Hands the pinned bounce pair of a short-lived context back (to the recycle bin, or to the driver) once its
+// uploads are done: several such contexts may be alive at once (the products of a sum-of-products sumcheck) and
+// 64 MiB of pinned memory each is neither cheap to allocate nor to hold.
+void bounce_release(zip_ctx *ctx) {
+    if (!ctx->bounce[0]) return;
+    if (ctx->recycle && ctx->bounce[1] && ctx->device >= 0 && ctx->device < kMaxDevices) {
+        RecycleBin &bin = g_recycle[ctx->device];
+        std::lock_guard<std::mutex> g(bin.mu);
+        if (!bin.bounce_cap) {
+            for (int i = 0; i < 2; i++) {
+                bin.bounce[i] = ctx->bounce[i];
+                ctx->bounce[i] = nullptr;
+            }
+            bin.bounce_cap = ctx->bounce_cap;
+        }
+    }
+    for (auto *&b : ctx->bounce) {
+        if (b) (void)hipHostFree(b);
+        b = nullptr;
+    }
+    ctx->bounce_cap = 0;
 }
 
 void parallel_memcpy(void *dst, const void *src, size_t bytes) {
@@ -2129,6 +2153,8 @@ int32_t zip_sumcheck_init(int32_t device, const uint64_t *const *mles, zip_mem_k
         if ((rc = pool_alloc(ctx, (size_t)(degree + 1) * elem, (void **)&s->evals_d))) break;
         if ((rc = pool_alloc(ctx, 16, (void **)&s->done_d))) break;
         if (hipMemsetAsync(s->done_d, 0, 16, ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
+        bounce_release(ctx);                  // the tables are up: nothing else of this handle goes through them
         s->evals_pinned = slab_take(device);  // null (all slots busy): the message goes through evals_d and a copy
         if (s->evals_pinned) memset(s->evals_pinned, 0, kSlabSlotBytes);
     } while (0);
@@ -2140,10 +2166,11 @@ int32_t zip_sumcheck_init(int32_t device, const uint64_t *const *mles, zip_mem_k
     return ZIP_OK;
 }
 
-int32_t zip_sumcheck_round(zip_sumcheck *s, const uint64_t *r_prev, uint64_t *evaluations_out) {
-    if (!s || !evaluations_out) return ZIP_ERR_NULL;
+int32_t zip_sumcheck_round_begin(zip_sumcheck *s, const uint64_t *r_prev) {
+    if (!s) return ZIP_ERR_NULL;
     zip_ctx *ctx = s->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (s->pending) return fail(ctx, ZIP_ERR_INVALID_PARAM, "the previous round has not been collected (zip_sumcheck_round_end)");
     if (s->round >= s->num_vars) return fail(ctx, ZIP_ERR_INVALID_PARAM, "Prover is not active");  // prover.rs:91-93
     if (s->round == 0 && r_prev) return fail(ctx, ZIP_ERR_INVALID_PARAM, "first round should be prover first.");
     if (s->round > 0 && !r_prev) return fail(ctx, ZIP_ERR_INVALID_PARAM, "verifier message is empty");
@@ -2161,6 +2188,16 @@ int32_t zip_sumcheck_round(zip_sumcheck *s, const uint64_t *r_prev, uint64_t *ev
     }
     if (rc) return rc;
     s->round++;
+    s->pending = true;
+    return ZIP_OK;
+}
+
+int32_t zip_sumcheck_round_end(zip_sumcheck *s, uint64_t *evaluations_out) {
+    if (!s || !evaluations_out) return ZIP_ERR_NULL;
+    zip_ctx *ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!s->pending) return fail(ctx, ZIP_ERR_INVALID_PARAM, "no round in flight (zip_sumcheck_round_begin)");
+    s->pending = false;
     const size_t msg_bytes = (size_t)(s->degree + 1) * s->fl * 8;
     if (s->evals_pinned) {
         // The kernel writes the message, then the round number, into host-mapped coherent memory: poll that word
@@ -2180,6 +2217,12 @@ int32_t zip_sumcheck_round(zip_sumcheck *s, const uint64_t *r_prev, uint64_t *ev
     HIP_TRY(ctx, hipMemcpyAsync(evaluations_out, s->evals_d, msg_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ZIP_OK;
+}
+
+int32_t zip_sumcheck_round(zip_sumcheck *s, const uint64_t *r_prev, uint64_t *evaluations_out) {
+    if (!s || !evaluations_out) return ZIP_ERR_NULL;
+    const int32_t rc = zip_sumcheck_round_begin(s, r_prev);
+    return rc ? rc : zip_sumcheck_round_end(s, evaluations_out);
 }
 
 const char *zip_sumcheck_last_error(const zip_sumcheck *s) { return s && s->ctx ? s->ctx->last_error.c_str() : ""; }

@@ -323,6 +323,30 @@ int32_t zinc_sumcheck_prove_ccs(zinc_transcript *transcript, const uint64_t *con
     });
 }
 
+int32_t zinc_sumcheck_prove_products(zinc_transcript *transcript, const uint64_t *const *mles, uint32_t n_mles,
+                                     uint32_t nvars, uint32_t degree, uint32_t n_products, const uint64_t *coeffs,
+                                     const uint32_t *masks, const uint64_t *modulus, uint32_t limbs, int32_t device,
+                                     uint64_t *msgs_out, uint64_t *randomness_out) {
+    if (!transcript || !mles || !coeffs || !masks || !msgs_out || !randomness_out) return ZINC_ERR_NULL;
+    return guarded([&] {
+        const FieldConfig f = FieldConfig::make(modulus, limbs);
+        std::vector<const uint64_t *> tables(mles, mles + n_mles);
+        std::vector<std::pair<Limbs, std::vector<uint32_t>>> products(n_products);
+        for (uint32_t p = 0; p < n_products; p++) {
+            products[p].first = load(coeffs + (size_t)p * limbs, limbs);
+            for (uint32_t j = 0; j < 32; j++)
+                if ((masks[p] >> j) & 1u) products[p].second.push_back(j);
+        }
+        const auto res = zinc::sumcheck::prove_as_subprotocol_products(transcript->t, tables, nvars, degree, products, f, device);
+        for (size_t r = 0; r < res.proof.msgs.size(); r++) {
+            for (uint32_t e = 0; e <= degree; e++)
+                for (uint32_t i = 0; i < limbs; i++)
+                    msgs_out[(r * (degree + 1) + e) * limbs + i] = res.proof.msgs[r][e][i];
+            for (uint32_t i = 0; i < limbs; i++) randomness_out[r * limbs + i] = res.randomness[r][i];
+        }
+    });
+}
+
 namespace {
 zinc::ccs::CCS_Z square_ccs(uint32_t t, uint32_t s) {
     zinc::ccs::CCS_Z ccs;

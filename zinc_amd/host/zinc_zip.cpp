@@ -876,6 +876,62 @@ sumcheck::ProverOutput sumcheck::prove_as_subprotocol_ccs(KeccakTranscript &tran
     return prove_as_subprotocol_impl(transcript, mles, nvars, degree, &comb, config, device);
 }
 
+sumcheck::ProverOutput sumcheck::prove_as_subprotocol_products(
+    KeccakTranscript &transcript, const std::vector<const uint64_t *> &mles, uint32_t nvars, uint32_t degree,
+    const std::vector<std::pair<Limbs, std::vector<uint32_t>>> &products, const FieldConfig &config, int device) {
+    transcript.absorb_random_field(config, map_to_field_u128(config, nvars, 0));  // sumcheck.rs:64-76
+    transcript.absorb_random_field(config, map_to_field_u128(config, degree, 0));
+    ProverOutput out;
+    if (nvars == 0) return out;
+    if (products.empty()) throw ZipError(ZipError::InvalidPcsParam, "no product");
+    const zip_field zf = config.to_abi();
+    struct Free {
+        void operator()(zip_sumcheck *p) const { zip_sumcheck_free(p); }
+    };
+    std::vector<std::unique_ptr<zip_sumcheck, Free>> provers;
+    for (const auto &[coeff, indices] : products) {
+        if (indices.empty() || indices.size() > 4)
+            throw ZipError(ZipError::InvalidPcsParam, "a product needs 1..4 multiplicands");
+        std::vector<const uint64_t *> tables;
+        for (uint32_t j : indices) {
+            if (j >= mles.size()) throw std::logic_error("index out of bounds: a product refers to a missing MLE");
+            tables.push_back(mles[j]);
+        }
+        zip_sumcheck_comb comb{};  // coeff * prod_{j < K-1} vals[j] * vals[K-1]
+        comb.n_terms = 1;
+        comb.term_mask[0] = (1u << (tables.size() - 1)) - 1u;
+        for (uint32_t i = 0; i < config.limbs; i++) comb.coeff[0][i] = coeff[i];
+        zip_sumcheck *raw = nullptr;
+        const int32_t rc = zip_sumcheck_init(device, tables.data(), ZIP_MEM_HOST, (uint32_t)tables.size(), nvars, degree, &comb, &zf, &raw);
+        if (rc) throw ZipError(rc == ZIP_ERR_INVALID_PARAM ? ZipError::InvalidPcsParam : ZipError::Device,
+                               std::string("zip_sumcheck_init: ") + zip_strerror(rc));
+        provers.emplace_back(raw);
+    }
+    std::vector<uint64_t> evals((size_t)(degree + 1) * config.limbs);
+    Limbs r{};
+    for (uint32_t round = 0; round < nvars; round++) {
+        for (auto &p : provers)
+            if (zip_sumcheck_round_begin(p.get(), round ? r.data() : nullptr))
+                throw ZipError(ZipError::Device, std::string("zip_sumcheck_round_begin: ") + zip_sumcheck_last_error(p.get()));
+        std::vector<Limbs> msg(degree + 1);
+        for (auto &p : provers) {
+            if (zip_sumcheck_round_end(p.get(), evals.data()))
+                throw ZipError(ZipError::Device, std::string("zip_sumcheck_round_end: ") + zip_sumcheck_last_error(p.get()));
+            for (uint32_t e = 0; e <= degree; e++) {
+                Limbs t{};
+                for (uint32_t i = 0; i < config.limbs; i++) t[i] = evals[(size_t)e * config.limbs + i];
+                config.add_assign(msg[e], t);
+            }
+        }
+        for (uint32_t e = 0; e <= degree; e++) transcript.absorb_random_field(config, msg[e]);
+        out.proof.msgs.push_back(std::move(msg));
+        r = transcript.get_challenge(config);
+        transcript.absorb_random_field(config, r);
+        out.randomness.push_back(r);
+    }
+    return out;
+}
+
 // ---------------------------------------------------------------------------- CCS
 ccs::SparseMatrix ccs::SparseMatrix::from_coeffs(uint32_t n_rows, uint32_t n_cols,
                                                  const std::vector<std::vector<std::pair<int64_t, uint32_t>>> &coeffs) {

@@ -283,6 +283,14 @@ ProverOutput prove_as_subprotocol_ccs(KeccakTranscript &transcript, const std::v
                                       uint32_t nvars, uint32_t degree, const std::vector<Limbs> &c,
                                       const std::vector<std::vector<uint32_t>> &S, const FieldConfig &config,
                                       int device = 0);
+// The same for a sum of products, comb(vals) = sum_p coeff_p * prod_{j in indices_p} vals[j] (rand_poly_comb_fn,
+// src/sumcheck/utils.rs:67-78; the workload of benches/sumcheck_benches.rs: 7 products of 2-4 fresh MLEs).  Each
+// product runs as its own device prover (at most 4 multiplicands each), all of them enqueued before any is
+// collected; the round message is the field sum of theirs.
+ProverOutput prove_as_subprotocol_products(KeccakTranscript &transcript, const std::vector<const uint64_t *> &mles,
+                                           uint32_t nvars, uint32_t degree,
+                                           const std::vector<std::pair<Limbs, std::vector<uint32_t>>> &products,
+                                           const FieldConfig &config, int device = 0);
 // SumCheckError / SpartanError (src/sumcheck.rs:28-38, src/zinc/errors.rs): what the verifier returns as Err
 struct SpartanError : std::runtime_error {
     enum Kind { SumCheckFailed, InvalidProofLength, MaxDegreeExceeded, PcsVerification } kind;

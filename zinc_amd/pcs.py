@@ -23,6 +23,7 @@ EXPORTED_SYMBOLS = (
     "zinc_zip_verify", "zinc_zip_evaluate", "zinc_commit_z_mle_and_prove_evaluation", "zinc_zip_proof_len",
     "zinc_zip_proof_num_roots", "zinc_zip_proof_read", "zinc_zip_proof_free", "zinc_zip_release_cached_contexts", "zinc_sumcheck_prove_product", "zinc_sumcheck_prove_ccs", "zinc_zip_data_download", "zinc_zip_data_upload", "zinc_merkle_tree_new",
     "zinc_prover_prove", "zinc_prover_prepare", "zinc_prepared_ccs_free", "zinc_verifier_verify",
+    "zinc_sumcheck_prove_products",
 )
 
 
@@ -117,6 +118,8 @@ def lib():
         L.zinc_prover_prepare.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_int32, C.POINTER(vp)]
         L.zinc_prepared_ccs_free.argtypes = [vp]
         L.zinc_prepared_ccs_free.restype = None
+        L.zinc_sumcheck_prove_products.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp,
+                                                   C.c_uint32, C.c_int32, vp, vp]
         L.zinc_verifier_verify.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_uint32,
                                            C.c_int32, vp, vp, vp, vp, C.c_int32, vp, C.c_size_t, vp, vp, C.c_size_t,
                                            vp, vp, vp]
@@ -438,6 +441,23 @@ def sumcheck_prove_ccs(transcript: KeccakTranscript, mles, degree: int, c, S, fi
     rand = np.zeros((nv, fl), np.uint64)
     _check(lib().zinc_sumcheck_prove_ccs(transcript._h, ptrs, K, nv, degree, len(S), cv.ctypes.data, masks.ctypes.data,
                                          field._m.ctypes.data, fl, device, msgs.ctypes.data, rand.ctypes.data))
+    return msgs, rand
+
+
+def sumcheck_prove_products(transcript: KeccakTranscript, mles, degree: int, masks, coeffs, field: FieldConfig,
+                            device: int = 0):
+    """prove_as_subprotocol with rand_poly_comb_fn (sumcheck/utils.rs:67-78): sum_p coeffs[p] * prod_{j in masks[p]} vals[j].
+    mles: [K, 2^nv, limbs] Montgomery limbs; coeffs: [P, limbs]; masks: P bit masks over the K MLEs."""
+    m = np.ascontiguousarray(mles, dtype=np.uint64)
+    K, n, fl = m.shape
+    nv = n.bit_length() - 1
+    ptrs = (C.c_void_p * K)(*[m[k].ctypes.data for k in range(K)])
+    mk = np.ascontiguousarray(masks, dtype=np.uint32)
+    cv = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(mk.size, fl)
+    msgs = np.zeros((nv, degree + 1, fl), np.uint64)
+    rand = np.zeros((nv, fl), np.uint64)
+    _check(lib().zinc_sumcheck_prove_products(transcript._h, ptrs, K, nv, degree, mk.size, cv.ctypes.data, mk.ctypes.data,
+                                              field._m.ctypes.data, fl, device, msgs.ctypes.data, rand.ctypes.data))
     return msgs, rand
 
 
