@@ -88,6 +88,12 @@ int32_t zip_device_count(void);
 /* zip_sumcheck / zip_ccs handles live for one proof; their device blocks are kept (per device, at most 4 GiB)
  * for the next handle instead of going back to hipFree / hipMalloc.  This returns them to the driver. */
 void zip_release_cached_memory(void);
+/* Host buffers the caller pins once (a reused proof or witness buffer) are reached by the DMA engines directly:
+ * every host transfer of this library first looks whether its buffer is pinned and only otherwise goes through the
+ * library's pinned bounce buffers and a host-side copy (~33 GB/s instead of PCIe's ~55).  ZIP_ERR_ALLOC when the
+ * range cannot be pinned (locked-memory limit); nothing else changes then. */
+int32_t zip_host_register(void *p, size_t bytes);
+void zip_host_unregister(void *p);
 
 /* Threading: calls on one ctx (and on its commitments) are serialised inside the library -- they
  * share one pinned staging buffer and one set of streams; distinct contexts run concurrently. */

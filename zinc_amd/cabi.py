@@ -24,7 +24,7 @@ ZIP_ERR_NULL = -7
 MEM_HOST, MEM_DEVICE = 0, 1
 
 EXPORTED_SYMBOLS = (
-    "zip_abi_version", "zip_strerror", "zip_device_count", "zip_release_cached_memory", "zip_ctx_create", "zip_ctx_destroy",
+    "zip_abi_version", "zip_strerror", "zip_device_count", "zip_release_cached_memory", "zip_host_register", "zip_host_unregister", "zip_ctx_create", "zip_ctx_destroy",
     "zip_ctx_last_error", "zip_ctx_synchronize", "zip_ctx_stream", "zip_commit", "zip_commitment_free",
     "zip_commitment_device_ptrs", "zip_commit_download", "zip_commitment_upload", "zip_open_testing",
     "zip_open_columns", "zip_open_eval", "zip_proof_len", "zip_open", "zip_sum_partials", "zip_merkle_trees",
@@ -122,6 +122,9 @@ def lib():
     L.zip_strerror.argtypes = [C.c_int32]
     L.zip_device_count.restype = C.c_int32
     L.zip_release_cached_memory.restype = None
+    L.zip_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    L.zip_host_unregister.argtypes = [C.c_void_p]
+    L.zip_host_unregister.restype = None
     L.zip_ctx_create.argtypes = [C.POINTER(ZipParams), C.POINTER(vp)]
     L.zip_ctx_destroy.argtypes = [vp]
     L.zip_ctx_destroy.restype = None

@@ -7,24 +7,81 @@
 
 #include <algorithm>
 #include <list>
+#include <map>
+#include <set>
 #include <mutex>
 
 #include <sys/mman.h>
 
 namespace zinc {
 
+namespace {
+// Freed proof- / witness-sized blocks are kept (exact sizes recur from proof to proof; at most 4 GiB) instead of
+// going back to the kernel: a fresh 383 MiB block costs as much in first-touch page faults as its PCIe transfer.
+struct BigBlockCache {
+    std::mutex mu;
+    std::multimap<size_t, void *> blocks;
+    size_t bytes = 0;
+    std::set<void *> pinned;  // blocks registered with the HIP runtime (unregistered before they are freed)
+};
+BigBlockCache g_big;
+void big_block_free(void *p) {  // g_big.mu held
+    if (g_big.pinned.erase(p)) zip_host_unregister(p);
+    std::free(p);
+}
+constexpr size_t kBigBlock = (size_t)16 << 20, kBigCacheCap = (size_t)4 << 30;
+}  // namespace
+
 void *byte_stream_alloc(size_t bytes) {
     void *p = nullptr;
-    if (bytes >= ((size_t)16 << 20)) {
+    if (bytes >= kBigBlock) {
+        {
+            std::lock_guard<std::mutex> g(g_big.mu);
+            auto it = g_big.blocks.find(bytes);
+            if (it != g_big.blocks.end()) {
+                p = it->second;
+                g_big.blocks.erase(it);
+                g_big.bytes -= bytes;
+                return p;
+            }
+        }
         if (posix_memalign(&p, (size_t)2 << 20, bytes) != 0) throw std::bad_alloc();
 #ifdef MADV_HUGEPAGE
         (void)madvise(p, bytes, MADV_HUGEPAGE);
 #endif
+        // pinned once, reused for every later proof of this size: the device then writes the proof straight into
+        // it (ZINC_HOST_NO_PIN=1 keeps the blocks pageable)
+        static const bool pin = std::getenv("ZINC_HOST_NO_PIN") == nullptr;
+        if (pin && zip_host_register(p, bytes) == ZIP_OK) {
+            std::lock_guard<std::mutex> g(g_big.mu);
+            g_big.pinned.insert(p);
+        }
         return p;
     }
     p = std::malloc(bytes ? bytes : 1);
     if (!p) throw std::bad_alloc();
     return p;
+}
+
+void byte_stream_free(void *p, size_t bytes) {
+    if (p && bytes >= kBigBlock) {
+        std::lock_guard<std::mutex> g(g_big.mu);
+        if (g_big.bytes + bytes <= kBigCacheCap) {
+            g_big.blocks.emplace(bytes, p);
+            g_big.bytes += bytes;
+            return;
+        }
+        big_block_free(p);
+        return;
+    }
+    std::free(p);
+}
+
+void byte_stream_release_cache() {
+    std::lock_guard<std::mutex> g(g_big.mu);
+    for (auto &kv : g_big.blocks) big_block_free(kv.second);
+    g_big.blocks.clear();
+    g_big.bytes = 0;
 }
 
 using u128 = unsigned __int128;
@@ -608,8 +665,12 @@ MultilinearZipParams MultilinearZip::setup(uint64_t poly_size, const RaaCode &co
 }
 
 void MultilinearZip::release_cached_contexts() {
-    std::lock_guard<std::mutex> g(ctx_cache_mu());
-    ctx_cache().clear();
+    {
+        std::lock_guard<std::mutex> g(ctx_cache_mu());
+        ctx_cache().clear();
+    }
+    byte_stream_release_cache();   // and the host blocks kept for the next proof
+    zip_release_cached_memory();   // and the device / pinned blocks of the per-proof handles
 }
 
 // validate_input (pcs/utils.rs:24-58)
@@ -788,17 +849,36 @@ Limbs MultilinearZip::evaluate(const MultilinearZipParams &pp, const int64_t *ev
 
 }  // namespace zip
 
+namespace {
+// ZINC_HOST_TIMING=1: stage times on stderr (tools/zinc_prover_times.py, tools/prover_pcs_step.py)
+struct PcsStageTimer {
+    bool on = std::getenv("ZINC_HOST_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[zinc]   pcs %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+}  // namespace
+
 zip::ZipProof zip::commit_z_mle_and_prove_evaluation(const LinearCodeSpec &lc_spec, const int64_t *z_evals, size_t m,
                                                      const Limbs *r_y, size_t r_y_len, KeccakTranscript &transcript,
                                                      const FieldConfig &config, int device) {
+    PcsStageTimer timer;
     KeccakSeedSource seeds(transcript);
     const RaaCode linear_code = RaaCode::make(lc_spec, m, seeds);               // prover.rs:313
     const MultilinearZipParams param = MultilinearZip::setup(m, linear_code, device);  // :314
+    timer.lap("RaaCode::new + setup");
     auto committed = MultilinearZip::commit(param, z_evals, m, param.num_vars);  // :315
+    timer.lap("commit");
     PcsTranscript pcs_transcript;                                                // :316 (fresh)
     ZipProof out;
     out.v = MultilinearZip::evaluate(param, z_evals, m, r_y, r_y_len, config);    // :317-319
+    timer.lap("evaluate");
     MultilinearZip::open(param, z_evals, m, param.num_vars, committed.first, r_y, r_y_len, config, pcs_transcript);  // :320
+    timer.lap("open");
     out.z_comm = std::move(committed.second);
     out.pcs_proof = pcs_transcript.into_proof();
     return out;

@@ -47,7 +47,8 @@ struct default_init_allocator {
     // Large blocks are 2 MiB aligned and marked for transparent huge pages: first-touch faults
     // (the kernel zero-filling fresh pages) are what bounds the arrival of a proof in host memory.
     T *allocate(size_t n) { return static_cast<T *>(big_alloc(n * sizeof(T))); }
-    void deallocate(T *p, size_t) { std::free(p); }
+    void deallocate(T *p, size_t n) { byte_stream_free_dispatch(p, n * sizeof(T)); }
+    static void byte_stream_free_dispatch(void *p, size_t bytes);
     template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
     template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
     bool operator==(const default_init_allocator &) const { return true; }
@@ -55,8 +56,12 @@ struct default_init_allocator {
     static void *big_alloc(size_t bytes);
 };
 void *byte_stream_alloc(size_t bytes);
+void byte_stream_free(void *p, size_t bytes);   // big blocks go to a small process-wide cache
+void byte_stream_release_cache();               // returns that cache to the system
 template <class T>
 void *default_init_allocator<T>::big_alloc(size_t bytes) { return byte_stream_alloc(bytes); }
+template <class T>
+void default_init_allocator<T>::byte_stream_free_dispatch(void *p, size_t bytes) { byte_stream_free(p, bytes); }
 using ByteStream = std::vector<uint8_t, default_init_allocator<uint8_t>>;
 using IntVec = std::vector<int64_t, default_init_allocator<int64_t>>;  // witness-sized: huge pages, no zero fill
 
