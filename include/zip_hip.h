@@ -296,6 +296,10 @@ int32_t zip_field_map_int256(zip_ctx *ctx, const uint64_t *values, uint32_t n, c
  * row_len == 1).  value_out: HOST, field->limbs Montgomery limbs. */
 int32_t zip_mle_eval(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_kind, const uint64_t *q0_mont,
                      const uint64_t *q1_mont, const zip_field *field, uint64_t *value_out);
+/* The same over the witness a host-side zip_commit left on the device with the commitment: the prover's
+ * z_mle.evaluate(r_y) between commit and open (src/zinc/prover.rs:315-320) without a second upload. */
+int32_t zip_commitment_mle_eval(zip_commitment *c, const uint64_t *q0_mont, const uint64_t *q1_mont,
+                                const zip_field *field, uint64_t *value_out);
 
 /* Row-sharded open: exact sum of n_parts partial results (after an all-gather).
  * uparts: n_parts * row_len * m_limbs u64 or NULL; fparts: n_parts * row_len * limbs u64 or NULL.

@@ -1956,6 +1956,16 @@ int32_t zip_verify(zip_ctx *ctx, const uint8_t *roots, const uint8_t *proof, zip
     return ZIP_OK;
 }
 
+int32_t zip_commitment_mle_eval(zip_commitment *c, const uint64_t *q0_mont, const uint64_t *q1_mont,
+                                const zip_field *field, uint64_t *value_out) {
+    if (!c) return ZIP_ERR_NULL;
+    zip_ctx *ctx = c->ctx;
+    if (!c->evals)
+        return fail(ctx, ZIP_ERR_INVALID_PARAM, "the commitment holds no witness (it was committed from device memory or uploaded)");
+    // c->evals went up on s_commit, and zip_commit waited for that stream before it returned
+    return zip_mle_eval(ctx, c->evals, ZIP_MEM_DEVICE, q0_mont, q1_mont, field, value_out);
+}
+
 int32_t zip_mle_eval(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_kind, const uint64_t *q0_mont,
                      const uint64_t *q1_mont, const zip_field *field, uint64_t *value_out) {
     if (!ctx || !value_out) return ZIP_ERR_NULL;

@@ -875,7 +875,17 @@ zip::ZipProof zip::commit_z_mle_and_prove_evaluation(const LinearCodeSpec &lc_sp
     timer.lap("commit");
     PcsTranscript pcs_transcript;                                                // :316 (fresh)
     ZipProof out;
-    out.v = MultilinearZip::evaluate(param, z_evals, m, r_y, r_y_len, config);    // :317-319
+    {   // :317-319, z_mle.map_to_field(config).evaluate(r_y): over the witness the commit left on the device
+        if (r_y_len != param.num_vars)
+            throw ZipError(ZipError::InvalidPcsParam, "IncorrectLength: the point does not have num_vars coordinates");
+        std::vector<uint64_t> q0, q1;
+        point_to_tensor(config, param.num_rows, r_y, r_y_len, q0, q1);
+        const zip_field zf = config.to_abi();
+        check(param.ctx.get(),
+              zip_commitment_mle_eval(committed.first.handle.get(), q0.empty() ? nullptr : q0.data(),
+                                      q1.empty() ? nullptr : q1.data(), &zf, out.v.data()),
+              "zip_commitment_mle_eval");
+    }
     timer.lap("evaluate");
     MultilinearZip::open(param, z_evals, m, param.num_vars, committed.first, r_y, r_y_len, config, pcs_transcript);  // :320
     timer.lap("open");
