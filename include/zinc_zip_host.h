@@ -143,6 +143,15 @@ int32_t zinc_sumcheck_prove_products(zinc_transcript *transcript, const uint64_t
                                      const uint32_t *masks, const uint64_t *modulus, uint32_t limbs, int32_t device,
                                      uint64_t *msgs_out, uint64_t *randomness_out);
 
+/* MLSumcheck::verify_as_subprotocol (src/sumcheck.rs:116-160) with check_and_generate_subclaim
+ * (src/sumcheck/verifier.rs:97-143), on the host (O(nvars * degree) field operations).  msgs: n_rounds messages of
+ * evals_per_round elements each.  point_out: nvars elements, expected_out: one (either may be NULL).
+ * ZINC_ERR_SPARTAN: SumCheckFailed / MaxDegreeExceeded / InvalidProofLength (zinc_last_error() says which). */
+#define ZINC_ERR_SPARTAN (-6)
+int32_t zinc_sumcheck_verify(zinc_transcript *transcript, uint32_t nvars, uint32_t degree, const uint64_t *claimed_sum,
+                             const uint64_t *msgs, uint32_t n_rounds, uint32_t evals_per_round, const uint64_t *modulus,
+                             uint32_t limbs, uint64_t *point_out, uint64_t *expected_out);
+
 /* ZincProver (src/zinc/prover.rs): Prover::prove (:50-88) when with_pcs != 0, else
  * prepare_for_random_field_piop + SpartanProver::prove (:130-161, what benches/spartan_benches.rs times).
  *   constraints   Statement_Z.constraints as CSR (zip_sparse_matrix, include/zip_hip.h), t matrices of
@@ -173,7 +182,6 @@ int32_t zinc_prover_prove(const zip_sparse_matrix *constraints, uint32_t t, uint
  * Proof fields as zinc_prover_prove returns them.  rx_ry_out: 2 s elements; e_y_out, gamma_out: one element (any
  * may be NULL).  ZINC_ERR_SPARTAN: a sumcheck or the final equation failed; ZINC_ERR_INVALID_OPEN: the Zip
  * verifier rejected; zinc_last_error() has the message. */
-#define ZINC_ERR_SPARTAN (-6)
 int32_t zinc_verifier_verify(const zip_sparse_matrix *constraints, uint32_t t, uint32_t s, uint32_t d, uint32_t q,
                              const uint32_t *s_masks, const int64_t *c, zinc_transcript *transcript, const uint64_t *modulus,
                              uint32_t limbs, int32_t device, zinc_prepared_ccs *prepared, const uint64_t *msgs1,

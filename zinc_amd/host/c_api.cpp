@@ -347,6 +347,28 @@ int32_t zinc_sumcheck_prove_products(zinc_transcript *transcript, const uint64_t
     });
 }
 
+int32_t zinc_sumcheck_verify(zinc_transcript *transcript, uint32_t nvars, uint32_t degree, const uint64_t *claimed_sum,
+                             const uint64_t *msgs, uint32_t n_rounds, uint32_t evals_per_round, const uint64_t *modulus,
+                             uint32_t limbs, uint64_t *point_out, uint64_t *expected_out) {
+    if (!transcript || !claimed_sum || (n_rounds && !msgs)) return ZINC_ERR_NULL;
+    return guarded([&] {
+        const FieldConfig f = FieldConfig::make(modulus, limbs);
+        zinc::sumcheck::SumcheckProof proof;
+        for (uint32_t r = 0; r < n_rounds; r++) {
+            proof.msgs.emplace_back();
+            for (uint32_t e = 0; e < evals_per_round; e++)
+                proof.msgs.back().push_back(load(msgs + ((size_t)r * evals_per_round + e) * limbs, limbs));
+        }
+        const zinc::sumcheck::SubClaim claim =
+            zinc::sumcheck::verify_as_subprotocol(transcript->t, nvars, degree, load(claimed_sum, limbs), proof, f);
+        if (point_out)
+            for (size_t i = 0; i < claim.point.size(); i++)
+                for (uint32_t k = 0; k < limbs; k++) point_out[i * limbs + k] = claim.point[i][k];
+        if (expected_out)
+            for (uint32_t k = 0; k < limbs; k++) expected_out[k] = claim.expected_evaluation[k];
+    });
+}
+
 namespace {
 zinc::ccs::CCS_Z square_ccs(uint32_t t, uint32_t s) {
     zinc::ccs::CCS_Z ccs;

@@ -1053,7 +1053,17 @@ sumcheck::ProverOutput sumcheck::prove_as_subprotocol_products(
     transcript.absorb_random_field(config, map_to_field_u128(config, degree, 0));
     ProverOutput out;
     if (nvars == 0) return out;
-    if (products.empty()) throw ZipError(ZipError::InvalidPcsParam, "no product");
+    if (products.empty()) {  // comb_fn == 0 (sumcheck/tests.rs:525-557): every round polynomial is the zero constant
+        for (uint32_t round = 0; round < nvars; round++) {
+            std::vector<Limbs> msg(degree + 1);
+            for (const Limbs &e : msg) transcript.absorb_random_field(config, e);
+            out.proof.msgs.push_back(std::move(msg));
+            const Limbs r = transcript.get_challenge(config);
+            transcript.absorb_random_field(config, r);
+            out.randomness.push_back(r);
+        }
+        return out;
+    }
     const zip_field zf = config.to_abi();
     struct Free {
         void operator()(zip_sumcheck *p) const { zip_sumcheck_free(p); }

@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "zinc_zip_verify", "zinc_zip_evaluate", "zinc_commit_z_mle_and_prove_evaluation", "zinc_zip_proof_len",
     "zinc_zip_proof_num_roots", "zinc_zip_proof_read", "zinc_zip_proof_free", "zinc_zip_release_cached_contexts", "zinc_sumcheck_prove_product", "zinc_sumcheck_prove_ccs", "zinc_zip_data_download", "zinc_zip_data_upload", "zinc_merkle_tree_new",
     "zinc_prover_prove", "zinc_prover_prepare", "zinc_prepared_ccs_free", "zinc_verifier_verify",
-    "zinc_sumcheck_prove_products",
+    "zinc_sumcheck_prove_products", "zinc_sumcheck_verify",
 )
 
 
@@ -118,6 +118,7 @@ def lib():
         L.zinc_prover_prepare.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_int32, C.POINTER(vp)]
         L.zinc_prepared_ccs_free.argtypes = [vp]
         L.zinc_prepared_ccs_free.restype = None
+        L.zinc_sumcheck_verify.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, vp]
         L.zinc_sumcheck_prove_products.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp,
                                                    C.c_uint32, C.c_int32, vp, vp]
         L.zinc_verifier_verify.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_uint32,
@@ -445,20 +446,39 @@ def sumcheck_prove_ccs(transcript: KeccakTranscript, mles, degree: int, c, S, fi
 
 
 def sumcheck_prove_products(transcript: KeccakTranscript, mles, degree: int, masks, coeffs, field: FieldConfig,
-                            device: int = 0):
+                            device: int = 0, nvars: int = None):
     """prove_as_subprotocol with rand_poly_comb_fn (sumcheck/utils.rs:67-78): sum_p coeffs[p] * prod_{j in masks[p]} vals[j].
     mles: [K, 2^nv, limbs] Montgomery limbs; coeffs: [P, limbs]; masks: P bit masks over the K MLEs."""
     m = np.ascontiguousarray(mles, dtype=np.uint64)
     K, n, fl = m.shape
-    nv = n.bit_length() - 1
-    ptrs = (C.c_void_p * K)(*[m[k].ctypes.data for k in range(K)])
+    nv = nvars if nvars is not None else n.bit_length() - 1
+    ptrs = (C.c_void_p * max(K, 1))(*[m[k].ctypes.data for k in range(K)])
     mk = np.ascontiguousarray(masks, dtype=np.uint32)
-    cv = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(mk.size, fl)
+    cv = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(mk.size, fl) if mk.size else np.zeros((1, fl), np.uint64)
     msgs = np.zeros((nv, degree + 1, fl), np.uint64)
     rand = np.zeros((nv, fl), np.uint64)
-    _check(lib().zinc_sumcheck_prove_products(transcript._h, ptrs, K, nv, degree, mk.size, cv.ctypes.data, mk.ctypes.data,
+    if not mk.size:
+        mk = np.zeros(1, np.uint32)  # (a valid pointer; n_products == 0 says nothing is read)
+        n_products = 0
+    else:
+        n_products = mk.size
+    _check(lib().zinc_sumcheck_prove_products(transcript._h, ptrs, K, nv, degree, n_products, cv.ctypes.data, mk.ctypes.data,
                                               field._m.ctypes.data, fl, device, msgs.ctypes.data, rand.ctypes.data))
     return msgs, rand
+
+
+def sumcheck_verify(transcript: KeccakTranscript, nvars: int, degree: int, claimed_sum, msgs, field: FieldConfig):
+    """MLSumcheck::verify_as_subprotocol -> (point [nvars, limbs], expected_evaluation [limbs]); raises SpartanError.
+    msgs: [rounds, evaluations per round, limbs] -- whatever the proof holds, also when that is the wrong shape."""
+    fl = field.limbs
+    m = np.ascontiguousarray(msgs, dtype=np.uint64).reshape(-1, np.shape(msgs)[1] if np.ndim(msgs) == 3 else 0, fl) \
+        if np.size(msgs) else np.zeros((0, 0, fl), np.uint64)
+    cs = np.ascontiguousarray(claimed_sum, dtype=np.uint64).reshape(fl)
+    point = np.zeros((max(nvars, 1), fl), np.uint64)
+    expected = np.zeros(fl, np.uint64)
+    _check(lib().zinc_sumcheck_verify(transcript._h, nvars, degree, cs.ctypes.data, m.ctypes.data if m.size else None,
+                                      m.shape[0], m.shape[1], field._m.ctypes.data, fl, point.ctypes.data, expected.ctypes.data))
+    return point[:nvars], expected
 
 
 class ZincProver:
