@@ -588,6 +588,9 @@ class PreparedCcs:
         self._h = handle
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().zinc_prepared_ccs_free(self._h)
-            self._h = None
+        try:  # (at interpreter shutdown the module globals may already be gone)
+            if getattr(self, "_h", None):
+                lib().zinc_prepared_ccs_free(self._h)
+                self._h = None
+        except Exception:
+            pass
