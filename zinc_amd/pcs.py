@@ -184,9 +184,12 @@ class KeccakTranscript:
         self._h = lib().zinc_transcript_new()
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().zinc_transcript_free(self._h)
-            self._h = None
+        try:  # (at interpreter shutdown the module globals may already be gone)
+            if getattr(self, "_h", None):
+                lib().zinc_transcript_free(self._h)
+                self._h = None
+        except Exception:
+            pass
 
     def absorb(self, data: bytes):
         lib().zinc_transcript_absorb(self._h, data, len(data))
@@ -240,9 +243,12 @@ class PcsTranscript:
         return lib().zinc_pcs_transcript_position(self._h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().zinc_pcs_transcript_free(self._h)
-            self._h = None
+        try:  # (at interpreter shutdown the module globals may already be gone)
+            if getattr(self, "_h", None):
+                lib().zinc_pcs_transcript_free(self._h)
+                self._h = None
+        except Exception:
+            pass
 
     def into_proof(self) -> np.ndarray:
         out = np.zeros(lib().zinc_pcs_transcript_len(self._h), np.uint8)
@@ -304,9 +310,12 @@ class MultilinearZipData:
         return cls(h, pp, True)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().zinc_zip_data_free(self._h)
-            self._h = None
+        try:  # (at interpreter shutdown the module globals may already be gone)
+            if getattr(self, "_h", None):
+                lib().zinc_zip_data_free(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 class MultilinearZipParams:
@@ -317,9 +326,12 @@ class MultilinearZipParams:
         self.num_vars, self.num_rows, self.row_len, self.codeword_len = [x.value for x in g]
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().zinc_zip_params_free(self._h)
-            self._h = None
+        try:  # (at interpreter shutdown the module globals may already be gone)
+            if getattr(self, "_h", None):
+                lib().zinc_zip_params_free(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 class MultilinearZip:
