@@ -19,3 +19,29 @@ def oracle():
 
     _oracle.lib()
     return _oracle
+
+
+def pytest_collection_finish(session):
+    """tests/test_gpu_cpp_mirror.py runs a separate C++ program.  It is built and run HERE, before any test has touched
+    the GPU: a process that has initialised HIP must not exec another program on the GPU boxes, and a forked child
+    that execs counts.  The test itself only looks at the stored result."""
+    if not any("test_gpu_cpp_mirror" in item.nodeid for item in session.items):
+        return
+    import subprocess
+    import tempfile
+
+    lib = os.path.join(ROOT, "zinc_amd", "lib")
+    out = {"returncode": None, "stdout": "", "stderr": ""}
+    try:
+        exe = os.path.join(tempfile.mkdtemp(prefix="zinc_cpp_"), "zinc_prover_test")
+        cc = subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", f"-I{ROOT}/include", f"-I{ROOT}/zinc_amd/host",
+                             os.path.join(ROOT, "tests", "cpp", "zinc_prover_test.cpp"), "-o", exe, f"-L{lib}", "-lzinc_zip",
+                             "-lzip_hip", f"-Wl,-rpath,{lib}"], capture_output=True, text=True, timeout=300)
+        if cc.returncode != 0:
+            out.update(returncode=cc.returncode, stderr="g++ failed:\n" + cc.stderr)
+        else:
+            res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+            out.update(returncode=res.returncode, stdout=res.stdout, stderr=res.stderr)
+    except Exception as e:  # noqa: BLE001
+        out.update(returncode=-1, stderr=repr(e))
+    session.config._zinc_cpp_mirror = out
