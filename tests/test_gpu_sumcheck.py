@@ -194,3 +194,25 @@ def test_sum_of_products_bad_shapes(mods):
         pcs.sumcheck_prove_products(pcs.KeccakTranscript(), big, 5, np.array([31], dtype=np.uint32), c1, field)
     with pytest.raises(pcs.ReferencePanic):   # a product refers to an MLE that does not exist
         pcs.sumcheck_prove_products(pcs.KeccakTranscript(), tables, 2, np.array([3, 1 << 7], dtype=np.uint32), coeffs, field)
+
+
+def test_round_begin_end_protocol(mods):
+    """zip_sumcheck_round_begin / _end: a round is enqueued once and collected once; begin + end == round."""
+    cabi, _ = mods
+    L = cabi.lib()
+    field = cabi.make_field(BENCH_MODULUS, 4)
+    tables, _, _ = _rand_poly_tables(BENCH_MODULUS, 4, 5, (2,), seed=3)
+    a = cabi.Sumcheck(tables, 5, 2, field)
+    b = cabi.Sumcheck(tables, 5, 2, field)
+    out = np.zeros((3, 4), dtype=np.uint64)
+    assert L.zip_sumcheck_round_end(a._h, out.ctypes.data) != 0          # nothing in flight
+    assert L.zip_sumcheck_round_begin(a._h, None) == 0
+    assert L.zip_sumcheck_round_begin(a._h, None) != 0                    # the first one has not been collected
+    assert L.zip_sumcheck_round_end(a._h, out.ctypes.data) == 0
+    assert np.array_equal(out, b.round())
+    r = np.array([5, 0, 0, 0], dtype=np.uint64)
+    assert L.zip_sumcheck_round_begin(a._h, r.ctypes.data) == 0
+    assert L.zip_sumcheck_round_end(a._h, out.ctypes.data) == 0
+    assert np.array_equal(out, b.round(r))
+    a.free()
+    b.free()
