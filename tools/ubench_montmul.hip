@@ -64,6 +64,52 @@ __device__ __forceinline__ void mont_mul32(const uint32_t (&a)[8], const uint32_
     for (int i = 0; i < 8; i++) out[i] = ge ? d[i] : t[i];
 }
 
+// CIOS on 64-bit limbs: multiplication and reduction interleaved row by row
+__device__ __forceinline__ void mont_mul_cios64(const uint64_t (&a)[4], const uint64_t (&b)[4], const FieldDev<4> &f,
+                                                uint64_t (&out)[4]) {
+    typedef unsigned __int128 u128;
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u128 x = (u128)a[j] * b[i] + t[j] + c;
+            t[j] = (uint64_t)x;
+            c = (uint64_t)(x >> 64);
+        }
+        u128 y = (u128)t[4] + c;
+        t[4] = (uint64_t)y;
+        t[5] = (uint64_t)(y >> 64);
+        const uint64_t m = t[0] * f.inv;
+        u128 x = (u128)m * f.modulus[0] + t[0];
+        c = (uint64_t)(x >> 64);
+#pragma unroll
+        for (int j = 1; j < 4; j++) {
+            x = (u128)m * f.modulus[j] + t[j] + c;
+            t[j - 1] = (uint64_t)x;
+            c = (uint64_t)(x >> 64);
+        }
+        y = (u128)t[4] + c;
+        t[3] = (uint64_t)y;
+        t[4] = t[5] + (uint64_t)(y >> 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = t[i];
+    if (t[4] || geq_n<4>(out, f.modulus)) sub_n<4>(out, f.modulus);
+}
+
+__global__ void kcios(const uint64_t *in, uint64_t *out, int iters, FieldDev<4> f) {
+    const size_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t a[4], b[4], t[4];
+    for (int k = 0; k < 4; k++) { a[k] = in[i * 8 + k]; b[k] = in[i * 8 + 4 + k]; }
+    for (int it = 0; it < iters; it++) {
+        mont_mul_cios64(a, b, f, t);
+        for (int k = 0; k < 4; k++) { a[k] = b[k]; b[k] = t[k]; }
+    }
+    for (int k = 0; k < 4; k++) out[i * 4 + k] = b[k];
+}
+
 __global__ void k64(const uint64_t *in, uint64_t *out, int iters, FieldDev<4> f) {
     const size_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t a[4], b[4], t[4];
@@ -114,8 +160,19 @@ int main() {
         hipEventSynchronize(e1); hipEventElapsedTime(&ms1, e0, e1);
         hipEventRecord(e0); hipLaunchKernelGGL(k32, dim3(blocks), dim3(threads), 0, 0, in, o2, iters, f, inv32); hipEventRecord(e1);
         hipEventSynchronize(e1); hipEventElapsedTime(&ms2, e0, e1);
-        printf("64-bit limbs: %.2f ms (%.1f G mont_mul/s)   32-bit Comba: %.2f ms (%.1f G mont_mul/s)\n", ms1,
-               n * (double)iters / ms1 / 1e6, ms2, n * (double)iters / ms2 / 1e6);
+        float ms3;
+        hipEventRecord(e0); hipLaunchKernelGGL(kcios, dim3(blocks), dim3(threads), 0, 0, in, o2, iters, f); hipEventRecord(e1);
+        hipEventSynchronize(e1); hipEventElapsedTime(&ms3, e0, e1);
+        {
+            std::vector<uint64_t> ra(n * 4), rb(n * 4);
+            hipMemcpy(ra.data(), o1, n * 32, hipMemcpyDeviceToHost);
+            hipMemcpy(rb.data(), o2, n * 32, hipMemcpyDeviceToHost);
+            printf("CIOS64 %s; ", memcmp(ra.data(), rb.data(), n * 32) ? "DIFFERS" : "identical");
+        }
+        hipEventRecord(e0); hipLaunchKernelGGL(k32, dim3(blocks), dim3(threads), 0, 0, in, o2, iters, f, inv32); hipEventRecord(e1);
+        hipEventSynchronize(e1); hipEventElapsedTime(&ms2, e0, e1);
+        printf("64-bit limbs (library): %.2f ms (%.1f G/s)   CIOS 64-bit: %.2f ms (%.1f G/s)   32-bit Comba: %.2f ms (%.1f G/s)\n", ms1,
+               n * (double)iters / ms1 / 1e6, ms3, n * (double)iters / ms3 / 1e6, ms2, n * (double)iters / ms2 / 1e6);
     }
     std::vector<uint64_t> r1(n * 4), r2(n * 4);
     hipMemcpy(r1.data(), o1, n * 32, hipMemcpyDeviceToHost);
