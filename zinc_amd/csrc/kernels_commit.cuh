@@ -28,7 +28,8 @@ struct CommitArgs {
     const int64_t *evals;
     const uint32_t *perm1;
     const uint32_t *perm2;
-    uint64_t *rows;
+    uint64_t *rows;    // [rows][cw][4] (Int<4>), or [rows][cw][2] when compact_rows
+    uint32_t compact_rows;  // 16-byte row entries (w0, w1, w2, sign): the values fit 96 bits, the rest is sign extension
     uint32_t *layers;  // 8 words per hash
     uint32_t *roots;   // [rows][8]
     uint32_t row_len;
@@ -151,13 +152,18 @@ struct StridedLeaves {
     uint32_t *tree;
     uint32_t cw, T, tid;
     uint32_t base = 0;  // first entry of the strip the butterfly covers (a multiple of E * T)
+    uint32_t compact = 0;  // CommitArgs.compact_rows (wave-uniform)
     template <int E0>
     __device__ __forceinline__ void store_row() {
         const uint32_t j = base + E0 * T + tid;
         const uint32_t s = (uint32_t)((int32_t)w2[E0] >> 31);
-        uint4 *o = reinterpret_cast<uint4 *>(out_row + (size_t)j * 4);
-        o[0] = make_uint4(w0[E0], w1[E0], w2[E0], s);  // sign extension to Int<4>
-        o[1] = make_uint4(s, s, s, s);
+        if (compact) {
+            *reinterpret_cast<uint4 *>(out_row + (size_t)j * 2) = make_uint4(w0[E0], w1[E0], w2[E0], s);
+        } else {
+            uint4 *o = reinterpret_cast<uint4 *>(out_row + (size_t)j * 4);
+            o[0] = make_uint4(w0[E0], w1[E0], w2[E0], s);  // sign extension to Int<4>
+            o[1] = make_uint4(s, s, s, s);
+        }
     }
     template <int E0>
     __device__ __forceinline__ void leaf(uint32_t (&h)[8]) {
@@ -338,7 +344,7 @@ __global__ void __launch_bounds__(1024, 5) raa_commit_kernel(CommitArgs a) {
         const uint32_t z = opaque_zero(row);
         const uint32_t tid = tid0 + z;
         const int64_t *in = a.evals + (size_t)row * row_len;
-        uint64_t *out_row = a.rows + (size_t)row * cw * 4;
+        uint64_t *out_row = a.rows + (size_t)row * cw * (a.compact_rows ? 2 : 4);
 
         const bool has_next = row + gridDim.x < a.num_rows;
         if (!(prefetch && round)) {
@@ -416,6 +422,7 @@ __global__ void __launch_bounds__(1024, 5) raa_commit_kernel(CommitArgs a) {
         if (active) {
             StridedLeaves<E> src;
             src.out_row = out_row;
+            src.compact = a.compact_rows;
             src.tree = HASH ? a.layers + (size_t)row * (2u * cw) * 8 : nullptr;
             src.cw = cw;
             src.T = a.nact;
@@ -495,7 +502,7 @@ __global__ void __launch_bounds__(1024, 4) raa_commit16_kernel(CommitArgs a) {
         const uint32_t z = opaque_zero(row);
         const uint32_t tid = tid0 + z;
         const int64_t *in = a.evals + (size_t)row * row_len;
-        uint64_t *out_row = a.rows + (size_t)row * cw * 4;
+        uint64_t *out_row = a.rows + (size_t)row * cw * (a.compact_rows ? 2 : 4);
 
         i128 v[E];
         // ---- pass 1: repeat + permute(pi1) + accumulate (witness from global / L2) ----
@@ -558,6 +565,7 @@ __global__ void __launch_bounds__(1024, 4) raa_commit16_kernel(CommitArgs a) {
             lds_barrier();
             StridedLeaves<8> src;
             src.out_row = out_row;
+            src.compact = a.compact_rows;
             src.tree = HASH ? a.layers + (size_t)row * (2u * cw) * 8 : nullptr;
             src.cw = cw;
             src.T = T;
@@ -581,6 +589,15 @@ __global__ void __launch_bounds__(1024, 4) raa_commit16_kernel(CommitArgs a) {
         }
         const bool last = row + gridDim.x >= a.num_rows;
         if (last || (round + 1) % a.rounds_per_chunk == 0) finish_chunk<HASH>(a, 4u, round, tid, T);
+    }
+}
+
+// [n][2] compact row entries (w0, w1, w2, sign as four 32-bit words) -> [n][4] Int<4> limbs
+__global__ void __launch_bounds__(256) expand_rows_kernel(const uint4 *in, uint4 *out, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 v = in[i];
+        out[2 * i] = v;
+        out[2 * i + 1] = make_uint4(v.w, v.w, v.w, v.w);
     }
 }
 

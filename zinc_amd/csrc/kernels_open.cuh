@@ -348,7 +348,8 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const uint64_t *upart
 // path record (8 + 32*depth bytes) is only 8-byte aligned in the stream.
 // ---------------------------------------------------------------------------
 struct OpenColsArgs {
-    const uint64_t *rows;    // [num_rows][cw][K]
+    const uint64_t *rows;    // [num_rows][cw][K], or [num_rows][cw][2] when compact_rows (see CommitArgs)
+    uint32_t compact_rows;
     const uint64_t *layers;  // [num_rows][2*cw][4]
     const uint32_t *cols;    // [n_cols] (device)
     uint8_t *out;            // wire stream of the openings
@@ -416,8 +417,15 @@ __global__ void __launch_bounds__(256) open_columns_kernel(OpenColsArgs a) {
         const uint32_t half = threadIdx.x & 1, rsub = threadIdx.x >> 1;  // two 16-byte halves per value
         if (rsub < nrows) {
             const uint32_t r = r0 + rsub;
-            const ulonglong2 v =
-                *reinterpret_cast<const ulonglong2 *>(a.rows + ((size_t)r * a.cw + col) * K + half * 2);
+            ulonglong2 v;
+            if (a.compact_rows) {  // (w0, w1, w2, sign): the upper half of the Int<4> is the sign word four times
+                const uint4 e = *reinterpret_cast<const uint4 *>(a.rows + ((size_t)r * a.cw + col) * 2);
+                const uint64_t ss = ((uint64_t)e.w << 32) | e.w;
+                v.x = half ? ss : ((uint64_t)e.y << 32) | e.x;
+                v.y = half ? ss : ((uint64_t)e.w << 32) | e.z;
+            } else {
+                v = *reinterpret_cast<const ulonglong2 *>(a.rows + ((size_t)r * a.cw + col) * K + half * 2);
+            }
             *reinterpret_cast<ulonglong2 *>(base + (size_t)r * 8 * K + half * 16) = v;
         }
     }

@@ -92,7 +92,8 @@ struct zip_ctx {
 
 struct zip_commitment {
     zip_ctx *ctx = nullptr;
-    uint64_t *rows = nullptr;   // [rows_local][cw][4]
+    uint64_t *rows = nullptr;   // [rows_local][cw][4], or [rows_local][cw][2] while compact_rows (see materialize_rows)
+    bool compact_rows = false;
     uint32_t *layers = nullptr;  // [rows_local][2cw][8] or null (commit_no_merkle)
     uint32_t *roots = nullptr;   // [rows_local][8] or null
     int64_t *evals = nullptr;    // device copy owned by the handle when the witness came from the host
@@ -854,6 +855,7 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
     if (n_cols == 0 || row_hi <= row_lo) return ZIP_OK;
     OpenColsArgs a{};
     a.rows = c->rows;
+    a.compact_rows = c->compact_rows ? 1u : 0u;
     a.layers = reinterpret_cast<const uint64_t *>(c->layers);
     a.cols = cols_dv;
     a.out = out_d;
@@ -1503,7 +1505,11 @@ int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_k
     c->ctx = ctx;
     int32_t rc = ZIP_OK;
     do {
-        c->rows_bytes = (size_t)R * cw * 32;
+        // A commit that will be opened keeps 16-byte row entries in HBM (half the row stores; the gather expands them
+        // on the way into the proof); encode_rows / commit_no_merkle is read back and stays Int<4>.
+        static const bool no_compact = getenv("ZIP_HIP_NO_COMPACT_ROWS") != nullptr;
+        c->compact_rows = with_merkle && !no_compact;
+        c->rows_bytes = (size_t)R * cw * (c->compact_rows ? 16 : 32);
         if ((rc = pool_alloc(ctx, c->rows_bytes, (void **)&c->rows))) break;
         if (with_merkle) {
             c->layers_bytes = (size_t)R * 2 * cw * 32;
@@ -1542,6 +1548,7 @@ int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_k
         a.perm1 = ctx->perm1_d;
         a.perm2 = ctx->perm2_d;
         a.rows = c->rows;
+        a.compact_rows = c->compact_rows ? 1u : 0u;
         a.layers = c->layers;
         a.row_len = C;
         a.cw = cw;
@@ -1601,15 +1608,42 @@ void zip_commitment_free(zip_commitment *c) {
     delete c;
 }
 
+static int32_t materialize_rows(zip_commitment *c);
+
 int32_t zip_commitment_device_ptrs(zip_commitment *c, uint64_t **rows, uint8_t **layers, uint8_t **roots) {
     if (!c) return ZIP_ERR_NULL;
     std::lock_guard<std::recursive_mutex> api_lock(c->ctx->api_mu);
     // work enqueued on the ctx stream (zip_ctx_stream) after this call sees complete data
     int32_t rc_ = wait_ready(c, c->ctx->stream);
     if (rc_) return rc_;
-    if (rows) *rows = c->rows;
+    if (rows) {
+        if ((rc_ = materialize_rows(c))) return rc_;
+        *rows = c->rows;
+    }
     if (layers) *layers = reinterpret_cast<uint8_t *>(c->layers);
     if (roots) *roots = reinterpret_cast<uint8_t *>(c->roots);
+    return ZIP_OK;
+}
+
+// One-way: the compact rows of a commitment become the Int<4> array the ABI promises to whoever looks at them
+// (zip_commit_download, zip_commitment_device_ptrs); afterwards the handle behaves like an uploaded one.
+static int32_t materialize_rows(zip_commitment *c) {
+    if (!c->compact_rows) return ZIP_OK;
+    zip_ctx *ctx = c->ctx;
+    int32_t rc = wait_ready(c, ctx->stream);
+    if (rc) return rc;
+    const uint64_t n = c->rows_bytes / 16;
+    void *full = nullptr;
+    if ((rc = pool_alloc(ctx, (size_t)n * 32, &full))) return rc;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 65535);
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(c->rows),
+                       static_cast<uint4 *>(full), n);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    pool_release(ctx, c->rows);
+    c->rows = static_cast<uint64_t *>(full);
+    c->rows_bytes = (size_t)n * 32;
+    c->compact_rows = false;
     return ZIP_OK;
 }
 
@@ -1624,7 +1658,9 @@ int32_t zip_commit_download(zip_commitment *c, uint64_t *rows_out, uint8_t *laye
         if (rc_) return rc_;
     }
     if (rows_out) {
-        int32_t rc_ = copy_d2h_bounced(ctx, rows_out, c->rows, c->rows_bytes, ctx->stream);
+        int32_t rc_ = materialize_rows(c);
+        if (rc_) return rc_;
+        rc_ = copy_d2h_bounced(ctx, rows_out, c->rows, c->rows_bytes, ctx->stream);
         if (rc_) return rc_;
     }
     if (layers_out) {
