@@ -115,7 +115,9 @@ int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_k
                    int32_t with_merkle, uint8_t *roots_out, zip_commitment **out);
 void zip_commitment_free(zip_commitment *c);
 
-/* Device views of the handle (zero-copy interop).  rows: row_count*cw*4 u64.
+/* Device views of the handle (zero-copy interop).  rows: row_count*cw*4 u64 -- asking for them expands the
+ * 16-byte entries a commitment keeps internally into this array once (a copy of row_count*cw*32 bytes on the
+ * device); pass rows == NULL if only the layers / roots are wanted.
  * layers: per row 2*cw hashes of 32 B (level k at hash offset 2cw-(2cw>>k), root at
  * 2cw-2, last slot padding).  roots: row_count*32 B.  Any out pointer may be NULL. */
 int32_t zip_commitment_device_ptrs(zip_commitment *c, uint64_t **rows, uint8_t **layers, uint8_t **roots);
