@@ -138,6 +138,14 @@ def main():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5A494E43)
     args = ap.parse_args()
 
+    if not args.no_cpu_baseline and int(os.environ.get("RANK", "0")) == 0:
+        # the checker library of the cpu_baseline leg is built (if stale) BEFORE anything touches the GPU:
+        # a GPU-initialised process must not fork + exec `make` on the GPU boxes
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle
+
+        _oracle.build()
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -201,7 +209,7 @@ def main():
             com.open(evals_d, coeffs, cols, q0, zf, out=proof)  # returns when the whole stream is in HBM
             if world > 1:
                 # the one exchange of the commit: every rank's Merkle roots
-                _, _, roots_ptr = com.device_ptrs()
+                roots_ptr = com.roots_ptr()  # rows=NULL: the 16-byte row entries are not expanded
                 mine = roots_view(torch, roots_ptr, per, dev)
                 dist.all_gather_into_tensor(roots_all, mine if backend == "nccl" else mine.cpu())
                 torch.cuda.current_stream().synchronize()  # the roots buffer returns to the pool below

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define ZIP_HIP_ABI_VERSION 1
+#define ZIP_HIP_ABI_VERSION 2
 
 /* status codes */
 #define ZIP_OK 0
@@ -114,6 +114,21 @@ void *zip_ctx_stream(zip_ctx *ctx);
 int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
                    int32_t with_merkle, uint8_t *roots_out, zip_commitment **out);
 void zip_commitment_free(zip_commitment *c);
+
+/* zip_commit (with Merkle trees) for a caller that already knows which columns it is going to open.  In the
+ * prover flow it does: ZincProver::commit_z_mle_and_prove_evaluation (src/zinc/prover.rs:305-328) opens with a
+ * FRESH PcsTranscript (prover.rs:316) and write_integers / write_merkle_proof never absorb
+ * (src/zip/pcs_transcript.rs:115-135,198-211), so the column indices of open (src/zip/pcs/open_z.rs:116-120) are
+ * a function of the field configuration alone and the shim can squeeze them before it commits.
+ * cols: HOST, n_cols indices < codeword_len (duplicates allowed).
+ * Same roots and the same handle semantics as zip_commit; the hint only lets the commit kernel skip the HBM
+ * stores no opening of those columns can read (about three quarters of the encoded rows and tree nodes at 1000
+ * of 8192 columns).  Whatever else is later asked of the handle -- other columns, zip_commit_download, the rows /
+ * layers device pointers -- first re-runs the commit in full from the witness, transparently; for that a DEVICE
+ * `evals` must stay valid and unchanged until the handle is freed.  Geometries below codeword_len 512 ignore
+ * the hint. */
+int32_t zip_commit_hinted(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
+                          const uint32_t *cols, uint32_t n_cols, uint8_t *roots_out, zip_commitment **out);
 
 /* Device views of the handle (zero-copy interop).  rows: row_count*cw*4 u64 -- asking for them expands the
  * 16-byte entries a commitment keeps internally into this array once (a copy of row_count*cw*32 bytes on the

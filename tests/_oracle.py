@@ -42,12 +42,17 @@ class Params(C.Structure):
     ]
 
 
+def _stale():
+    return not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
+        os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("zip_oracle.c", "zip_oracle.h"))
+
+
 def build(force=False):
-    if force or not os.path.exists(_LIB_PATH) or (
-        os.path.getmtime(_LIB_PATH) < max(
-            os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("zip_oracle.c", "zip_oracle.h"))
-    ):
-        subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+    """Runs `make -C oracle` when the library is missing or older than its sources.  This forks and execs, which a
+    process that has initialised the GPU must never do on the GPU boxes: call it FIRST (pytest_configure, the top of
+    bench.main(), smoke() and the tools do), never lazily."""
+    if force or _stale():
+        subprocess.run(["make", "-B", "-C", ORACLE_DIR], check=True, capture_output=True)
     return _LIB_PATH
 
 
@@ -55,9 +60,12 @@ _lib = None
 
 
 def lib():
+    """The loaded oracle.  Never builds: a missing library is an error that names the fix."""
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} is missing: run `make -C oracle` (or _oracle.build()) before any GPU call")
+        _lib = C.CDLL(_LIB_PATH)
         _lib.orc_tr_get_u64.restype = C.c_uint64
         _lib.orc_proof_len.restype = C.c_size_t
     return _lib

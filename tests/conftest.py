@@ -11,6 +11,11 @@ for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle (the checker) is built HERE, before any test can have touched the GPU: _oracle.lib() never builds,
+    # because a fork + exec of `make` from a process that has initialised HIP takes a GPU box down.
+    import _oracle
+
+    _oracle.build()
 
 
 @pytest.fixture(scope="session")

@@ -69,6 +69,10 @@ def test_commit_open_2pow24(env):
     q0 = orc.build_eq_x_r(f, point[nv - lr:])
     proof = com.open(d_evals, coeffs, cols, q0, cabi.make_field(BENCH_MODULUS, 4))
     assert proof.size == z.proof_len(4) == 4096 * 64 + 1000 * 4096 * (32 + 8 + 32 * 13) + 4096 * 32  # commit.rs:712-737
+    # byte diff of ten opened-column blocks of the 1.74 GiB stream, at a size where the gather IS pipelined
+    # (four chunks behind the persistent commit kernel): values and whole path records of the sampled rows
+    _diff_proof_columns(z, evals, proof, cols, [0, 1, 2, 250, 499, 500, 777, 997, 998, 999],
+                        [0, 1, 255, 256, 2047, 4095, 1234, 3333], z.row_len * 64)
     ev = z.mle_eval(f, evals, point)
     assert z.verify(f, roots, point, ev, proof, check_merkle=True) == 0
     bad = proof.copy()
@@ -99,8 +103,8 @@ def test_commit_open_2pow24(env):
 
 
 def test_commit_2pow26_geometry_sampled(env):
-    """configs[3] geometry (row_len 8192, codeword 16384, depth 14; the variant that parks t2 in the
-    output row), on a 1024-row slice = what one of 8 GPUs owns of a 2^26 commit."""
+    """configs[3] geometry (row_len 8192, codeword 16384, depth 14: raa_commit16_kernel), on a 1024-row slice =
+    what one of 8 GPUs owns of a 2^26 commit."""
     cabi, torch = env
     nv, rows = 26, 1024
     zfull = orc.Zip(nv, perm1=np.zeros(1, np.uint32), perm2=np.zeros(1, np.uint32))
@@ -114,3 +118,120 @@ def test_commit_2pow26_geometry_sampled(env):
     rows_t = _dev_view(torch, rows_p, (rows, z.codeword_len * 4), "<i8")
     layers_t = _dev_view(torch, layers_p, (rows, 2 * z.codeword_len * 32), "|u1")
     _check_sampled_rows(z, evals, rows_t, layers_t, roots, [0, 511, 1023])
+
+
+def _squeeze_open_inputs(z, f, nv):
+    """What a fresh PcsTranscript yields at the start of open (open_z.rs:104,118): the proximity coefficients and
+    the column indices; plus q0 for point = [1; nv] as in the bench (zip_benches.rs:143)."""
+    fs = orc.new_transcript()
+    coeffs = np.zeros(z.num_rows, dtype=np.int64)
+    for r in range(z.num_rows):
+        orc.lib().orc_tr_get_integer_challenge(orc.C.byref(fs), 1, coeffs[r:].ctypes.data_as(orc.C.POINTER(orc.C.c_uint64)))
+    cols = np.array([orc.get_challenge(fs, f) % (1 << 32) % z.codeword_len for _ in range(1000)], dtype=np.uint32)
+    point = orc.point_to_field(f, [1] * nv)
+    lr = z.num_rows.bit_length() - 1
+    return coeffs, cols, point, orc.build_eq_x_r(f, point[nv - lr:]), orc.build_eq_x_r(f, point[: nv - lr])
+
+
+def _host(x):
+    return x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
+
+
+def _diff_proof_columns(z, evals, proof_t, cols, pick_cols, pick_rows, u_bytes):
+    """Byte diff of opened-column blocks of a device-resident proof against oracle-built rows and paths
+    (open_z.rs:124-143): for the picked openings, the value and the whole path record of every picked row."""
+    per_col = z.num_rows * (32 + 8 + 32 * z.depth)
+    rec_bytes = 8 + 32 * z.depth
+    enc, trees = {}, {}
+    for r in pick_rows:
+        rc, e = z.encode_row(evals[r * z.row_len:(r + 1) * z.row_len])
+        assert rc == 0
+        enc[r], trees[r] = e, orc.merkle_tree(z.depth, e)
+    for i in pick_cols:
+        c = int(cols[i])
+        base = u_bytes + i * per_col
+        for r in pick_rows:
+            val = _host(proof_t[base + r * 32: base + (r + 1) * 32])
+            assert val.tobytes() == enc[r][c].astype("<u8").tobytes(), (i, c, r)
+            o = base + z.num_rows * 32 + r * rec_bytes
+            rec = _host(proof_t[o: o + rec_bytes])
+            assert int.from_bytes(rec[:8].tobytes(), "big") == z.depth
+            assert rec[8:].tobytes() == orc.merkle_path(z.depth, trees[r][: (2 << z.depth) - 1], c).tobytes(), (i, c, r)
+
+
+def test_commit_open_2pow26_full_on_one_gpu(env):
+    """configs[3] at its stated size on ONE device: 2^26 coefficients = 8192 rows x 8192, codeword 16384, depth 14
+    (0.5 GiB witness, 2 GiB of 16-byte row entries, 8 GiB of trees, a 3.7 GiB proof).  Sampled rows / trees / roots
+    against the oracle, determinism, exact proof length (commit.rs:712-737), sampled proof blocks byte for byte,
+    and the device verifier on the whole stream (every byte of it is read there)."""
+    cabi, torch = env
+    nv = 26
+    z = orc.Zip(nv)
+    assert (z.row_len, z.num_rows, z.codeword_len, z.depth) == (8192, 8192, 16384, 14)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    evals = orc.splitmix64(0x5A494E43 + 26, 1 << nv)
+    coeffs, cols, point, q0, q1 = _squeeze_open_inputs(z, f, nv)
+    ctx = cabi.ZipContext(nv, z.perm1, z.perm2)
+    d_evals = torch.from_numpy(evals).cuda()
+    sample = [0, 1, 255, 256, 4095, 4096, 8191, 5555]
+    # plain commit: everything materialised
+    com, roots = ctx.commit(d_evals)
+    _, layers_p, _ = com.device_ptrs(rows=False)
+    ctx.synchronize()
+    layers_t = _dev_view(torch, layers_p, (z.num_rows, 2 * z.codeword_len * 32), "|u1")
+    for r in sample:
+        rc, enc = z.encode_row(evals[r * z.row_len:(r + 1) * z.row_len])
+        assert rc == 0
+        tree = orc.merkle_tree(z.depth, enc)
+        got = layers_t[r].cpu().numpy().reshape(2 * z.codeword_len, 32)
+        assert np.array_equal(got[: 2 * z.codeword_len - 1], tree), r
+        assert np.array_equal(roots[r], tree[-1]), r
+    proof = torch.empty(ctx.proof_len(1000, 4), dtype=torch.uint8, device="cuda")
+    assert proof.numel() == z.proof_len(4) == 8192 * 64 + 1000 * 8192 * (32 + 8 + 32 * 14) + 8192 * 32
+    com.open(d_evals, coeffs, cols, q0, zf, out=proof)
+    ctx.synchronize()
+    u_bytes = z.row_len * 64
+    _diff_proof_columns(z, evals, proof, cols, [0, 1, 499, 998, 999], sample, u_bytes)
+    ev = z.mle_eval(f, evals, point)
+    ev_limbs = np.array(orc.int_to_limbs(ev, 4), dtype=np.uint64)
+    rep = ctx.verify(roots, proof, coeffs, cols, q0, q1, ev_limbs, zf)
+    assert rep == {"verdict": cabi.VERIFY_ACCEPT, "column": 0, "bad_merkle_paths": 0, "malformed_paths": 0}
+    com.free()
+    # the hinted commit (columns known up front): same roots (determinism, commit.rs:253-283), same proof bytes
+    com2, roots2 = ctx.commit(d_evals, hint_cols=cols)
+    assert np.array_equal(roots, roots2)
+    proof2 = torch.empty_like(proof)
+    com2.open(d_evals, coeffs, cols, q0, zf, out=proof2)
+    ctx.synchronize()
+    assert torch.equal(proof, proof2)
+    proof2[proof2.numel() // 2] ^= 1
+    rep = ctx.verify(roots, proof2, coeffs, cols, q0, q1, ev_limbs, zf)
+    assert rep["verdict"] != cabi.VERIFY_ACCEPT
+    com2.free()
+
+
+@pytest.mark.parametrize("hinted", [False, True])
+def test_commit_open_2pow22_pipelined_gather_byte_diff(env, hinted):
+    """2^22 with the default chunking (two chunks: the gather of the first runs beside the hashing of the second):
+    sampled proof blocks byte for byte against oracle-built rows and paths, with and without the opening hint."""
+    cabi, torch = env
+    nv = 22
+    z = orc.Zip(nv)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    evals = orc.splitmix64(0x5A494E43 + 22, 1 << nv)
+    coeffs, cols, point, q0, q1 = _squeeze_open_inputs(z, f, nv)
+    ctx = cabi.ZipContext(nv, z.perm1, z.perm2)
+    d_evals = torch.from_numpy(evals).cuda()
+    proof = torch.empty(ctx.proof_len(1000, 4), dtype=torch.uint8, device="cuda")
+    com, _ = ctx.commit(d_evals, want_roots=False, hint_cols=cols if hinted else None)  # asynchronous
+    com.open(d_evals, coeffs, cols, q0, zf, out=proof)
+    ctx.synchronize()
+    _diff_proof_columns(z, evals, proof, cols, [0, 1, 333, 500, 666, 998, 999], [0, 1, 255, 256, 1023, 1024, 2047],
+                        z.row_len * 64)
+    _, _, roots = com.download(rows=False, layers=False)
+    ev = z.mle_eval(f, evals, point)
+    rep = ctx.verify(roots, proof, coeffs, cols, q0, q1, np.array(orc.int_to_limbs(ev, 4), dtype=np.uint64), zf)
+    assert rep == {"verdict": cabi.VERIFY_ACCEPT, "column": 0, "bad_merkle_paths": 0, "malformed_paths": 0}
+    com.free()

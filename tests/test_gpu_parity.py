@@ -81,7 +81,8 @@ def test_commit_device_resident_input(cabi):
 
 
 def test_commit_large_codeword_global_t2_path(cabi):
-    """cw = 16384 (the 2^26 geometry) uses the variant that parks t2 in the output row."""
+    """cw = 16384 (the 2^26 geometry): raa_commit16_kernel -- t2 compacted into LDS, the output through an 8x8
+    transpose inside every 8-lane group, its second half parked in the dead t2 planes."""
     z = orc.Zip(16, geometry=(8192, 8, 16384))
     evals = _witness(16)
     rows_o, layers_o, roots_o = z.commit(evals)
@@ -355,3 +356,50 @@ def test_open_and_verify_on_the_2pow26_geometry(cabi):
     assert z.verify(f, roots, point, ev, proof) == 0
     rep = ctx.verify(roots, proof, coeffs, cols, q0, q1, np.array(orc.int_to_limbs(ev, 4), dtype=np.uint64), zf)
     assert rep["verdict"] == cabi.VERIFY_ACCEPT and rep["bad_merkle_paths"] == 0
+
+
+@pytest.mark.parametrize("geometry", [(16, None), (17, None), (20, None), (17, (8192, 16, 16384)), (12, None)])
+def test_hinted_commit_opens_bit_exact_and_completes_itself(cabi, geometry):
+    """zip_commit_hinted: the commit kernel skips every store the hinted openings cannot read (the columns are known
+    before the commit in the prover flow, src/zinc/prover.rs:316).  Roots and the proof of the hinted columns are the
+    oracle's byte for byte; asking for anything else (other columns, a download) completes the handle first and is
+    again the oracle's.  (2^12: codeword 128 < 512, the hint is ignored.)"""
+    nv, geo = geometry
+    z = orc.Zip(nv, geometry=geo) if geo else orc.Zip(nv)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    evals = _witness(nv, seed=21)
+    point = orc.point_to_field(f, np.arange(-4, nv - 4, dtype=np.int64))
+    rows_o, layers_o, roots_o = z.commit(evals)
+    proof_o, cols, coeffs = z.open(f, evals, rows_o, layers_o, point, orc.new_transcript())
+    lr = z.num_rows.bit_length() - 1
+    q0 = orc.build_eq_x_r(f, point[nv - lr:])
+    ctx = _ctx(cabi, z)
+    # a poisoned pool: stale bytes of an earlier commit must never reach the proof
+    junk, _ = ctx.commit(_witness(nv, seed=99))
+    ctx.synchronize()
+    junk.free()
+    com, roots = ctx.commit(evals, hint_cols=cols)
+    assert np.array_equal(roots, roots_o)
+    proof = com.open(evals, coeffs, cols, q0, zf)
+    assert np.array_equal(proof, proof_o)
+    # different columns: not covered by the hint
+    other = ((cols.astype(np.int64) * 7 + 3) % z.codeword_len).astype(np.uint32)
+    wire = com.open_columns(other)
+    per_col = z.num_rows * (32 + 8 + 32 * z.depth)
+    for i in (0, 1, len(other) // 2, len(other) - 1):
+        c = int(other[i])
+        got = wire[i * per_col:(i + 1) * per_col]
+        vals = got[: z.num_rows * 32].reshape(z.num_rows, 32)
+        rec = got[z.num_rows * 32:].reshape(z.num_rows, 8 + 32 * z.depth)
+        for r in (0, z.num_rows - 1):
+            assert vals[r].tobytes() == rows_o[r * z.codeword_len + c].astype("<u8").tobytes()
+            assert rec[r, 8:].tobytes() == orc.merkle_path(z.depth, layers_o[r], c).tobytes()
+    rows, layers, roots2 = com.download()
+    assert np.array_equal(rows, rows_o) and np.array_equal(roots2, roots_o)
+    assert np.array_equal(layers, layers_o[:, : 2 * z.codeword_len - 2])
+    com.free()
+    # a hinted handle that is downloaded straight away
+    com, _ = ctx.commit(evals, hint_cols=cols[:3])
+    rows, layers, _ = com.download()
+    assert np.array_equal(rows, rows_o) and np.array_equal(layers, layers_o[:, : 2 * z.codeword_len - 2])

@@ -12,6 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _oracle as orc  # noqa: E402
+
+orc.build()  # before the first GPU call: a GPU-initialised process must not fork + exec make
 from zinc_amd import pcs  # noqa: E402
 
 nv = int(sys.argv[1]) if len(sys.argv) > 1 else 20

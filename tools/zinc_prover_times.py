@@ -22,6 +22,10 @@ ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--oracle", action="store_true")
 ap.add_argument("--prime", choices=["bench", "stark", "256"], default="stark")
 args = ap.parse_args()
+if args.oracle:
+    import _oracle  # noqa: E402
+
+    _oracle.build()  # before the first GPU call: a GPU-initialised process must not fork + exec make
 
 PRIMES = {"bench": bench.BENCH_MODULUS,
           "stark": 3618502788666131213697322783095070105623107215331596699973092056135872020481,  # spartan_benches.rs:161

@@ -25,7 +25,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 
 EXPORTED_SYMBOLS = (
     "zip_abi_version", "zip_strerror", "zip_device_count", "zip_release_cached_memory", "zip_host_register", "zip_host_unregister", "zip_ctx_create", "zip_ctx_destroy",
-    "zip_ctx_last_error", "zip_ctx_synchronize", "zip_ctx_stream", "zip_commit", "zip_commitment_free",
+    "zip_ctx_last_error", "zip_ctx_synchronize", "zip_ctx_stream", "zip_commit", "zip_commit_hinted", "zip_commitment_free",
     "zip_commitment_device_ptrs", "zip_commit_download", "zip_commitment_upload", "zip_open_testing",
     "zip_open_columns", "zip_open_eval", "zip_proof_len", "zip_open", "zip_sum_partials", "zip_merkle_trees",
     "zip_ctx_set_profiling", "zip_ctx_profile_read", "zip_verify", "zip_mle_eval", "zip_commitment_mle_eval", "zip_field_map_int256",
@@ -134,6 +134,7 @@ def lib():
     L.zip_ctx_stream.argtypes = [vp]
     L.zip_ctx_stream.restype = vp
     L.zip_commit.argtypes = [vp, i64p, C.c_size_t, C.c_int, C.c_int32, u8p, C.POINTER(vp)]
+    L.zip_commit_hinted.argtypes = [vp, i64p, C.c_size_t, C.c_int, u32p, C.c_uint32, u8p, C.POINTER(vp)]
     L.zip_verify.argtypes = [vp, u8p, vp, C.c_int, C.c_size_t, i64p, u32p, C.c_uint32, u64p, u64p, u64p,
                              C.POINTER(ZipField), C.POINTER(VerifyReport)]
     L.zip_mle_eval.argtypes = [vp, i64p, C.c_int, u64p, u64p, C.POINTER(ZipField), u64p]
@@ -177,7 +178,7 @@ def lib():
     L.zip_merkle_trees.argtypes = [C.c_int32, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u8p]
     L.zip_ctx_set_profiling.argtypes = [vp, C.c_int32]
     L.zip_ctx_profile_read.argtypes = [vp, C.POINTER(KernelTime), C.c_uint32]
-    for fn in ("zip_ctx_create", "zip_ctx_synchronize", "zip_commit", "zip_commitment_device_ptrs",
+    for fn in ("zip_ctx_create", "zip_ctx_synchronize", "zip_commit", "zip_commit_hinted", "zip_commitment_device_ptrs",
                "zip_commit_download", "zip_commitment_upload", "zip_open_testing", "zip_open_columns",
                "zip_open_eval", "zip_open", "zip_sum_partials", "zip_merkle_trees", "zip_ctx_set_profiling",
                "zip_ctx_profile_read", "zip_verify", "zip_mle_eval", "zip_field_map_int256", "zip_open_stream", "zip_sumcheck_init", "zip_sumcheck_round"):
@@ -278,15 +279,23 @@ class ZipContext:
     def stream(self):
         return lib().zip_ctx_stream(self._h)
 
-    def commit(self, evals, with_merkle=True, want_roots=True):
-        """MultilinearZip::commit / commit_no_merkle.  evals: int64 numpy array or CUDA tensor."""
+    def commit(self, evals, with_merkle=True, want_roots=True, hint_cols=None):
+        """MultilinearZip::commit / commit_no_merkle.  evals: int64 numpy array or CUDA tensor.
+        hint_cols: the column indices the caller is going to open (zip_commit_hinted): same roots, same handle, but
+        the kernel skips the stores no opening of those columns reads."""
         ptr, kind = _ptr(evals)
         n = evals.size if isinstance(evals, np.ndarray) else evals.numel()
         roots = np.zeros((self.rows_local, 32), dtype=np.uint8) if (with_merkle and want_roots) else None
         h = C.c_void_p()
-        rc = lib().zip_commit(self._h, ptr, n, kind, int(with_merkle), roots.ctypes.data if roots is not None else None,
-                              C.byref(h))
-        self._check(rc, "zip_commit")
+        rp = roots.ctypes.data if roots is not None else None
+        if hint_cols is not None:
+            assert with_merkle, "a hint only makes sense for a commitment that will be opened"
+            hc = np.ascontiguousarray(hint_cols, dtype=np.uint32)
+            rc = lib().zip_commit_hinted(self._h, ptr, n, kind, hc.ctypes.data, hc.size, rp, C.byref(h))
+            self._check(rc, "zip_commit_hinted")
+        else:
+            rc = lib().zip_commit(self._h, ptr, n, kind, int(with_merkle), rp, C.byref(h))
+            self._check(rc, "zip_commit")
         return Commitment(self, h, bool(with_merkle)), roots
 
     def upload_commitment(self, rows, layers=None, roots=None):
@@ -399,11 +408,18 @@ class Commitment:
         except Exception:
             pass
 
-    def device_ptrs(self):
+    def device_ptrs(self, rows=True):
+        """(rows, layers, roots) device pointers.  Asking for `rows` expands the handle's 16-byte entries into the
+        Int<4> array once (a full-size copy on the device); callers that only need layers / roots pass rows=False
+        and get None for the first element."""
         r, l, t = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        self.ctx._check(lib().zip_commitment_device_ptrs(self._h, C.byref(r), C.byref(l), C.byref(t)),
+        self.ctx._check(lib().zip_commitment_device_ptrs(self._h, C.byref(r) if rows else None, C.byref(l), C.byref(t)),
                         "zip_commitment_device_ptrs")
-        return r.value, l.value, t.value
+        return (r.value if rows else None), l.value, t.value
+
+    def roots_ptr(self):
+        """Device pointer of the row_count x 32-byte Merkle roots (never materialises the rows)."""
+        return self.device_ptrs(rows=False)[2]
 
     def download(self, rows=True, layers=True, roots=True):
         c = self.ctx

@@ -38,6 +38,11 @@ struct CommitArgs {
     uint32_t num_rows;          // rows of this ctx (the kernel is persistent: row = blockIdx.x + i * gridDim.x)
     uint32_t rounds_per_chunk;  // a chunk = this many consecutive rounds of gridDim.x rows
     uint32_t *chunk_done;       // [chunks] arrival counters, or null
+    // Opening hint (zip_commit_hinted): bitmaps of what an open of the hinted columns will ever read, or null =
+    // store everything.  Words: [V: cw bits, entry j is opened][N0: cw bits][N1: cw/2][N2: cw/4], N_l bit i = node i
+    // of level l is the sibling of an opened path ((i ^ 1) == c >> l for an opened column c).  Levels >= 3 are
+    // always stored (the in-kernel upper levels read level 3 back, and above it nearly every node is needed).
+    const uint32_t *need;
 #ifdef ZIPK_DEBUG_STAMPS
     unsigned long long *stamps;  // tools/ubench_pipeline.hip: [chunk][workgroup] wall-clock of each arrival
 #endif
@@ -145,7 +150,7 @@ __device__ __forceinline__ void subtree_hash(Src &src, uint32_t (&h)[8]) {
 // line).  Sibling leaves then sit in NEIGHBOUR LANES; the in-thread subtree becomes a
 // butterfly: at level l a lane exchanges one child hash with lane t ^ 2^(l-1) and ends up
 // with the node of step E0 + (t mod 2^l).  Every lane still hashes E leaves, E/2 ... 1 nodes.
-template <int E>
+template <int E, bool MASKED = false>
 struct StridedLeaves {
     uint32_t w0[E], w1[E], w2[E];  // 96-bit two's-complement values of the lane's E entries
     uint64_t *out_row;
@@ -153,8 +158,13 @@ struct StridedLeaves {
     uint32_t cw, T, tid;
     uint32_t base = 0;  // first entry of the strip the butterfly covers (a multiple of E * T)
     uint32_t compact = 0;  // CommitArgs.compact_rows (wave-uniform)
+    // MASKED (zip_commit_hinted): which of this lane's stores an opening of the hinted columns can ever read
+    // (row invariant, see store_mask below): bit e = row entry of step e, bit 8 + e = its leaf hash, bits 16.. =
+    // the lane's level-1 nodes (E0 / 2), bits 24.. = its level-2 nodes (E0 / 4).
+    uint32_t smask = 0xFFFFFFFFu;
     template <int E0>
     __device__ __forceinline__ void store_row() {
+        if (MASKED && !(smask & (1u << E0))) return;
         const uint32_t j = base + E0 * T + tid;
         const uint32_t s = (uint32_t)((int32_t)w2[E0] >> 31);
         if (compact) {
@@ -169,18 +179,46 @@ struct StridedLeaves {
     __device__ __forceinline__ void leaf(uint32_t (&h)[8]) {
         store_row<E0>();
         blake3_leaf_sext96(w0[E0], w1[E0], w2[E0], h);
-        store_hash(tree + (size_t)(base + E0 * T + tid) * 8, h);
+        if (!MASKED || (smask & (0x100u << E0))) store_hash(tree + (size_t)(base + E0 * T + tid) * 8, h);
     }
     // node of local level LVL computed by this lane: step E0 + (tid mod 2^LVL)
     template <int LVL, int E0>
     __device__ __forceinline__ void store(const uint32_t (&h)[8]) {
+        if (MASKED && LVL <= 2 && !(smask & ((LVL == 1 ? 0x10000u : 0x1000000u) << (E0 >> LVL)))) return;
         const uint32_t e = E0 + (tid & ((1u << LVL) - 1u));
         store_hash(tree + ((size_t)level_off(cw, LVL) + ((base + e * T + tid) >> LVL)) * 8, h);
     }
 };
 
-template <int E, int E0>
-__device__ __forceinline__ void store_rows_only(StridedLeaves<E> &src) {
+// The row-invariant store mask of one lane (StridedLeaves::smask) from the hint bitmaps of CommitArgs.need:
+// the lane's entry of step e is j = base + e * T + tid, its level-l node of group E0 (a multiple of 2^l) is
+// node (base + (E0 + tid mod 2^l) * T + tid) >> l.
+template <int E>
+__device__ __forceinline__ uint32_t store_mask(const uint32_t *need, uint32_t cw, uint32_t base, uint32_t T, uint32_t tid) {
+    if (!need) return 0xFFFFFFFFu;
+    const uint32_t *nv = need, *n0 = nv + (cw + 31) / 32, *n1 = n0 + (cw + 31) / 32, *n2 = n1 + (cw / 2 + 31) / 32;
+    uint32_t m = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint32_t j = base + e * T + tid;
+        m |= ((nv[j >> 5] >> (j & 31)) & 1u) << e;
+        m |= ((n0[j >> 5] >> (j & 31)) & 1u) << (8 + e);
+    }
+#pragma unroll
+    for (int g = 0; g < E / 2; g++) {
+        const uint32_t i = (base + (2 * g + (tid & 1u)) * T + tid) >> 1;
+        m |= ((n1[i >> 5] >> (i & 31)) & 1u) << (16 + g);
+    }
+#pragma unroll
+    for (int g = 0; g < E / 4; g++) {
+        const uint32_t i = (base + (4 * g + (tid & 3u)) * T + tid) >> 2;
+        m |= ((n2[i >> 5] >> (i & 31)) & 1u) << (24 + g);
+    }
+    return m;
+}
+
+template <int E, int E0, class Src>
+__device__ __forceinline__ void store_rows_only(Src &src) {
     if constexpr (E0 < E) {
         src.template store_row<E0>();
         store_rows_only<E, E0 + 1>(src);
@@ -294,8 +332,12 @@ __device__ __forceinline__ uint32_t opaque_zero(uint32_t dep) {
 // (second __launch_bounds__ argument = waves per SIMD) leaves a quarter of every SIMD register
 // file to the consumer kernels.  At 128 VGPRs the file is full and nothing can co-reside
 // (measured: a probe kernel on another stream then only runs when this kernel ends).
-template <int E, bool HASH>
-__global__ void __launch_bounds__(1024, 5) raa_commit_kernel(CommitArgs a) {
+// MASKED = the commit carries an opening hint (CommitArgs.need): stores the hinted openings can never read are
+// predicated off by a per-lane, row-invariant bit mask.  That variant needs one VGPR more than the 96 of the
+// plain one and is allowed 104 (4 x 104 of the 512 per SIMD still leave room for three gather waves, and the
+// gather's LDS image limits it to two workgroups per CU beside this kernel anyway).
+template <int E, bool HASH, bool MASKED = false>
+__global__ void __launch_bounds__(1024, MASKED ? 4 : 5) raa_commit_kernel(CommitArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int LOGE = (E == 1) ? 0 : (E == 2) ? 1 : (E == 4) ? 2 : 3;
     static_assert((1 << LOGE) == E && E <= 8, "E must be 1, 2, 4 or 8");
@@ -324,6 +366,8 @@ __global__ void __launch_bounds__(1024, 5) raa_commit_kernel(CommitArgs a) {
         }
         pidx[e] = v1 | (v2 << 16);
     }
+    // ... the lane's store mask under an opening hint ...
+    const uint32_t smask = (MASKED && active) ? store_mask<E>(a.need, cw, 0u, a.nact, tid0) : 0xFFFFFFFFu;
     // ... and the NEXT witness row, fetched during the scan passes of the current one (rep = 2
     // geometry: row_len == NPF * blockDim; anything else takes the direct path).
     constexpr int NPF = (E >= 2) ? E / 2 : 1;
@@ -420,13 +464,14 @@ __global__ void __launch_bounds__(1024, 5) raa_commit_kernel(CommitArgs a) {
         lds_barrier();
         ZIPK_PH(ph_a);
         if (active) {
-            StridedLeaves<E> src;
+            StridedLeaves<E, MASKED> src;
             src.out_row = out_row;
             src.compact = a.compact_rows;
             src.tree = HASH ? a.layers + (size_t)row * (2u * cw) * 8 : nullptr;
             src.cw = cw;
             src.T = a.nact;
             src.tid = tid;
+            src.smask = smask;
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 const uint32_t j = e * a.nact + tid;
@@ -465,21 +510,52 @@ __global__ void __launch_bounds__(1024, 5) raa_commit_kernel(CommitArgs a) {
 //   t2[j] = P[j/16] + L[j]   (P = exclusive prefix of the thread that owns j, |L| < 2^67)
 // so bits 64.. of t2[j] differ from those of P[j/16] by at most +-9.  LDS holds the low 64 bits per
 // entry (planes, 128 KB), that difference as one byte per entry (16 KB) and the high word of P per
-// thread (2 KB): 146.5 KB, and pass 2 gathers pi2 from LDS like the smaller geometries do -- no
+// thread (4 KB): 148.5 KB, and pass 2 gathers pi2 from LDS like the smaller geometries do -- no
 // round trip of t2 through L2 and no store-draining barriers.  The witness row (64 KB) no longer
 // fits beside it and is gathered from global memory (L2) at the start of pass 1.
-// The output phase reuses the butterfly of raa_commit_kernel<8>: the row is emitted as two strips
-// of 8192 entries, each transposed through LDS (over the dead t2) to strided ownership.
+//
+// Output phase: the 196 KB of final values fit LDS even less, so there is NO workgroup-wide
+// transposition here.  A thread owns 16 consecutive entries = two aligned 8-entry subtrees, and the
+// eight lanes 8m..8m+7 of a wave own 16 such subtrees; an 8x8 transpose INSIDE each 8-lane group
+// (three xor-shuffle stages, registers only) hands lane 8m+i, at step s, entry i of the subtree of
+// lane 8m+s: sibling leaves sit in neighbour lanes, which is all the butterfly of raa_commit_kernel
+// needs, and the eight lanes of a group store 128 contiguous bytes of rows / 256 of leaf hashes per
+// instruction.  The row is emitted in two phases (entries 0..7 and 8..15 of every thread); the
+// second half waits in the thread's own slots of the dead t2 planes (written and read back by the
+// same thread: no barrier) instead of in 48 registers -- the previous variant (two 8192-entry strips
+// through LDS, three more barriers per row) spilled 59 VGPRs to scratch.
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kC16_T = 1024, kC16_PS = kC16_T + 2;  // plane stride of the 16 t2 planes
-constexpr uint32_t kC16_PS8 = kC16_T + 4;                // plane stride of the 8 output planes of one strip
 constexpr size_t kC16_LDS = 512 + (size_t)16 * kC16_PS * 8 + (size_t)16 * kC16_PS + (size_t)kC16_T * 4;
 
-template <bool HASH>
+// One stage of the 8x8 transpose over the lanes of an 8-lane group: registers r and r | 2^B are
+// exchanged with lane ^ 2^B (lane bit B clear keeps x[r], set keeps x[r | 2^B]).  After B = 0, 1, 2
+// lane i holds in x[s] what lane s held in x[i].
+// (compile-time recursion instead of loops: with constant indices from the start the arrays become registers in
+// the first SROA run; behind a not yet unrolled loop the optimiser first turns `up ? x[r] : x[r2]` into a load
+// from a selected ADDRESS, and the arrays then stay in scratch memory for good)
+template <int B, int P = 0>
+__device__ __forceinline__ void transpose8_stage(uint32_t (&x)[8], bool up) {
+    if constexpr (P < 4) {
+        constexpr int r = ((P >> B) << (B + 1)) | (P & ((1 << B) - 1)), r2 = r | (1 << B);
+        const uint32_t lo = x[r], hi = x[r2];
+        const uint32_t rcv = __shfl_xor(up ? lo : hi, 1 << B, 64);
+        x[r] = up ? rcv : lo;
+        x[r2] = up ? hi : rcv;
+        transpose8_stage<B, P + 1>(x, up);
+    }
+}
+__device__ __forceinline__ void transpose8(uint32_t (&x)[8], uint32_t lane) {
+    transpose8_stage<0>(x, lane & 1u);
+    transpose8_stage<1>(x, (lane >> 1) & 1u);
+    transpose8_stage<2>(x, (lane >> 2) & 1u);
+}
+
+template <bool HASH, bool MASKED = false>
 __global__ void __launch_bounds__(1024, 4) raa_commit16_kernel(CommitArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int E = 16;
-    constexpr uint32_t T = kC16_T, PS = kC16_PS, PS8 = kC16_PS8;
+    constexpr uint32_t T = kC16_T, PS = kC16_PS;
     const uint32_t tid0 = threadIdx.x;
     const uint32_t cw = a.cw, row_len = a.row_len;  // 16384, 8192
 
@@ -487,15 +563,13 @@ __global__ void __launch_bounds__(1024, 4) raa_commit16_kernel(CommitArgs a) {
     uint64_t *t2lo = reinterpret_cast<uint64_t *>(smem + 512);           // [16][PS]
     int8_t *t2dh = reinterpret_cast<int8_t *>(t2lo + (size_t)E * PS);     // [16][PS]
     int32_t *ghi = reinterpret_cast<int32_t *>(t2dh + (size_t)E * PS);    // [T]: bits 64.. of P[thread]
-    // output strips (phase B) overlay the same memory
-    uint64_t *o_lo = reinterpret_cast<uint64_t *>(smem + 512);            // [8][PS8]
-    uint32_t *o_hi = reinterpret_cast<uint32_t *>(o_lo + (size_t)8 * PS8);  // [8][PS8]
+    // second half of the outputs (phase B) waits in the dead t2 planes
+    uint64_t *park_lo = reinterpret_cast<uint64_t *>(smem + 512);         // [8][PS]
+    uint32_t *park_hi = reinterpret_cast<uint32_t *>(park_lo + (size_t)8 * PS);  // [8][PS]
 
-    // row-invariant: pi1 source index (13 bits) | pi2 source entry (14 bits) per owned entry
-    uint32_t pidx[E];
-#pragma unroll
-    for (int e = 0; e < E; e++)
-        pidx[e] = (a.perm1[tid0 * E + e] & (row_len - 1)) | (a.perm2[tid0 * E + e] << 13);
+    // row-invariant store masks of the two output phases under an opening hint
+    const uint32_t smask0 = MASKED ? store_mask<8>(a.need, cw, 0u, 16u, (tid0 & ~7u) * 16u + (tid0 & 7u)) : 0xFFFFFFFFu;
+    const uint32_t smask1 = MASKED ? store_mask<8>(a.need, cw, 0u, 16u, (tid0 & ~7u) * 16u + 8u + (tid0 & 7u)) : 0xFFFFFFFFu;
 
     uint32_t round = 0;
     for (uint32_t row = blockIdx.x; row < a.num_rows; row += gridDim.x, round++) {
@@ -504,14 +578,33 @@ __global__ void __launch_bounds__(1024, 4) raa_commit16_kernel(CommitArgs a) {
         const int64_t *in = a.evals + (size_t)row * row_len;
         uint64_t *out_row = a.rows + (size_t)row * cw * (a.compact_rows ? 2 : 4);
 
+        // The thread's permutation indices are re-read every row (2 x 64 bytes per thread from tables that live
+        // in L2; `tid` is opaque so the loads stay in the loop): held in registers across the hash phase, their
+        // 16 VGPRs were what pushed this kernel over its 128-register budget into scratch memory.
+        uint32_t p2[E];
         i128 v[E];
         // ---- pass 1: repeat + permute(pi1) + accumulate (witness from global / L2) ----
+        {
+            const uint4 *q1 = reinterpret_cast<const uint4 *>(a.perm1 + (size_t)tid * E);
+            const uint4 *q2 = reinterpret_cast<const uint4 *>(a.perm2 + (size_t)tid * E);
 #pragma unroll
-        for (int e = 0; e < E; e++) v[e] = (i128)in[pidx[e] & 0x1FFFu];
+            for (int k = 0; k < E / 4; k++) {
+                const uint4 s1 = q1[k], s2 = q2[k];
+                v[4 * k + 0] = (i128)in[s1.x & (row_len - 1)];
+                v[4 * k + 1] = (i128)in[s1.y & (row_len - 1)];
+                v[4 * k + 2] = (i128)in[s1.z & (row_len - 1)];
+                v[4 * k + 3] = (i128)in[s1.w & (row_len - 1)];
+                p2[4 * k + 0] = s2.x;
+                p2[4 * k + 1] = s2.y;
+                p2[4 * k + 2] = s2.z;
+                p2[4 * k + 3] = s2.w;
+            }
+        }
 #pragma unroll
         for (int e = 1; e < E; e++) v[e] += v[e - 1];
         {
-            if (round) lds_barrier();  // the previous row's output strips have been consumed
+            // (a thread reaches the barrier inside only after it has read back its parked outputs of the
+            // previous row, so the t2 stores below cannot overtake anybody's reads)
             const i128 pre = block_exclusive_scan_i96(v[E - 1], wave_tot, 0);
             const int32_t phi = (int32_t)(uint32_t)((u128)pre >> 64);
             ghi[tid] = phi;
@@ -526,7 +619,7 @@ __global__ void __launch_bounds__(1024, 4) raa_commit16_kernel(CommitArgs a) {
         // ---- pass 2: permute(pi2) + accumulate ----
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            const uint32_t j = pidx[e] >> 13;
+            const uint32_t j = p2[e];
             const uint32_t slot = (j & 15u) * PS + (j >> 4);
             const uint64_t lo = t2lo[slot];
             const int64_t hi = (int64_t)(ghi[j >> 4] + (int32_t)t2dh[slot]);
@@ -535,50 +628,54 @@ __global__ void __launch_bounds__(1024, 4) raa_commit16_kernel(CommitArgs a) {
 #pragma unroll
         for (int e = 1; e < E; e++) v[e] += v[e - 1];
         {
-            // the barrier inside also orders the t2 reads above before the strip stores below
+            // the barrier inside also orders everybody's t2 reads above before the parking stores below
             const i128 pre = block_exclusive_scan_i96(v[E - 1], wave_tot, 1);
 #pragma unroll
             for (int e = 0; e < E; e++) v[e] += pre;
         }
-        // the values wait in registers while the other strip is hashed: keep the 96 significant bits only
-        uint64_t flo[E];
-        uint32_t fhi[E];
+        // park entries 8..15 in this thread's own slots
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            flo[e] = (uint64_t)v[e];
-            fhi[e] = (uint32_t)((u128)v[e] >> 64);
+        for (int e = 8; e < E; e++) {
+            park_lo[(e - 8) * PS + tid] = (uint64_t)v[e];
+            park_hi[(e - 8) * PS + tid] = (uint32_t)((u128)v[e] >> 64);
         }
-        // ---- output: two strips of 8192 entries, each through LDS to strided ownership ----
-#pragma unroll 1
-        for (uint32_t h = 0; h < 2; h++) {
-            if (h) lds_barrier();  // strip 0 has been read by every lane
-            if ((tid >> 9) == h) {
-                const uint32_t t9 = tid & 511u;
+        // ---- output: two phases of 8 entries per thread, 8x8 lane-group transpose, butterfly ----
+        uint32_t x0[8], x1[8], x2[8];
 #pragma unroll
-                for (int e = 0; e < E; e++) {
-                    const uint32_t jj = t9 * E + e;  // entry inside the strip
-                    const uint32_t slot = (jj & 7u) * PS8 + (jj >> 3);
-                    o_lo[slot] = flo[e];
-                    o_hi[slot] = fhi[e];
+        for (int e = 0; e < 8; e++) {
+            x0[e] = (uint32_t)(uint64_t)v[e];
+            x1[e] = (uint32_t)((uint64_t)v[e] >> 32);
+            x2[e] = (uint32_t)((u128)v[e] >> 64);
+        }
+        // (both phases unrolled: arrays carried around a rolled loop stay in scratch memory)
+#pragma unroll
+        for (uint32_t q = 0; q < 2; q++) {
+            if (q) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const uint64_t lo = park_lo[e * PS + tid];
+                    x0[e] = (uint32_t)lo;
+                    x1[e] = (uint32_t)(lo >> 32);
+                    x2[e] = park_hi[e * PS + tid];
                 }
             }
-            lds_barrier();
-            StridedLeaves<8> src;
+            transpose8(x0, tid);
+            transpose8(x1, tid);
+            transpose8(x2, tid);
+            StridedLeaves<8, MASKED> src;
             src.out_row = out_row;
             src.compact = a.compact_rows;
             src.tree = HASH ? a.layers + (size_t)row * (2u * cw) * 8 : nullptr;
             src.cw = cw;
-            src.T = T;
-            src.tid = tid;
-            src.base = h * 8192u;
+            src.T = 16;  // entry of step s = 16 s + src.tid (the subtree of lane 8m+s, see above)
+            // wave base + 128 (lane / 8) + 8 q + (lane % 8): the low three bits are the lane's, as the butterfly needs
+            src.tid = (tid & ~7u) * 16u + q * 8u + (tid & 7u);
+            src.smask = q ? smask1 : smask0;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const uint32_t jj = e * T + tid;
-                const uint32_t slot = (jj & 7u) * PS8 + (jj >> 3);
-                const uint64_t lo = o_lo[slot];
-                src.w0[e] = (uint32_t)lo;
-                src.w1[e] = (uint32_t)(lo >> 32);
-                src.w2[e] = o_hi[slot];
+                src.w0[e] = x0[e];
+                src.w1[e] = x1[e];
+                src.w2[e] = x2[e];
             }
             if (HASH) {
                 uint32_t top[8];

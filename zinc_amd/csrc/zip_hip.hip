@@ -70,6 +70,7 @@ struct zip_ctx {
     // zip_open_stream: two pinned bounce buffers the proof leaves the device through
     unsigned char *bounce[2] = {nullptr, nullptr};
     size_t bounce_cap = 0;
+    std::vector<unsigned char *> hint_free;  // pinned kHintBytes blocks of dead hinted commitments
     std::string last_error;
     // private plumbing context of a zip_sumcheck / zip_ccs: its blocks go to the process-wide recycle bin
     // when it dies and are taken from there first (these handles live for one proof, hipMalloc is ~ms)
@@ -105,6 +106,16 @@ struct zip_commitment {
     hipEvent_t zeroed = nullptr;     // counters reset (consumers must not look at stale values)
     hipEvent_t done = nullptr;       // whole commit finished
     std::vector<hipEvent_t> aux;     // other events owned by the handle, recycled with it
+    // zip_commit_hinted: the kernel only stored what an opening of the hinted columns reads.  `hint_cols` is the
+    // set (bit c = column c was hinted); anything else asked of the handle first re-runs the commit in full
+    // (rematerialize) from the witness: `evals` above, or the caller's device array `evals_ref`.
+    bool hinted = false;
+    std::vector<uint32_t> hint_cols;
+    unsigned char *hint_h = nullptr;  // pinned staging of the bitmaps (returns to ctx->hint_free)
+    uint32_t *need_d = nullptr;       // device bitmaps (CommitArgs.need)
+    const int64_t *evals_ref = nullptr;
+    CommitArgs args{};                // the launch, for the re-run
+    uint32_t grid = 0;
 };
 
 // Prover state of one sumcheck (ProverState, src/sumcheck/prover.rs:25-37) on the device.
@@ -621,19 +632,28 @@ FieldDev<FL> to_dev(const HostField &h) {
     return d;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the function ON ONE DEVICE: remembered per
+// (function, device), under a lock -- contexts of different devices (and threads) share these launch helpers.
+int32_t ensure_dynamic_lds(zip_ctx *ctx, const void *kern, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> granted;
+    std::lock_guard<std::mutex> g(mu);
+    size_t &have = granted[std::make_pair(kern, ctx->device)];
+    if (bytes > have) {
+        HIP_TRY(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
+    return ZIP_OK;
+}
+
 // ------------------------------------------------------------------ commit dispatch
 // Persistent launch: as many workgroups as stay resident together (at most one per row).
-template <int E, bool HASH>
+template <int E, bool HASH, bool MASKED = false>
 int32_t launch_commit(zip_ctx *ctx, const CommitArgs &a, uint32_t threads, uint32_t grid, hipStream_t st) {
     // wave totals + E planes of (threads + 32/E) slots of 12 bytes + the witness row
     const size_t lds = 512 + (size_t)E * (threads + 32 / E) * 12 + (size_t)a.row_len * 8;
-    auto kern = raa_commit_kernel<E, HASH>;
-    static size_t lds_attr = 0;  // per instantiation
-    if (lds > lds_attr) {
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_attr = lds;
-    }
+    auto kern = raa_commit_kernel<E, HASH, MASKED>;
+    if (int32_t rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
     LaunchTimer t(ctx, HASH ? "raa_commit_kernel" : "raa_encode_kernel", st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
     HIP_TRY(ctx, hipGetLastError());
@@ -641,15 +661,10 @@ int32_t launch_commit(zip_ctx *ctx, const CommitArgs &a, uint32_t threads, uint3
 }
 
 // cw = 16384: raa_commit16_kernel (t2 compacted into LDS, 1024 threads x 16 entries)
-template <bool HASH>
+template <bool HASH, bool MASKED = false>
 int32_t launch_commit16(zip_ctx *ctx, const CommitArgs &a, uint32_t grid, hipStream_t st) {
-    auto kern = raa_commit16_kernel<HASH>;
-    static bool attr = false;
-    if (!attr) {
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC16_LDS));
-        attr = true;
-    }
+    auto kern = raa_commit16_kernel<HASH, MASKED>;
+    if (int32_t rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), kC16_LDS)) return rc;
     LaunchTimer t(ctx, HASH ? "raa_commit_kernel" : "raa_encode_kernel", st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), kC16_LDS, st, a);
     HIP_TRY(ctx, hipGetLastError());
@@ -678,10 +693,19 @@ uint32_t commit_wgs_per_cu(const CommitGeom &g) {
     return k ? k : 1;
 }
 
+// geometries whose commit kernel has a hint-masked variant (smaller ones store everything: the hint is dropped)
+bool commit_supports_hint(uint32_t cw) { return cw >= 512; }
+constexpr size_t kHintBytes = 8192;  // >= 4 * ((cw + 31) / 32 * 2 + cw / 64 + cw / 128 + 2) for cw <= 16384
+
 template <bool HASH>
 int32_t dispatch_commit(zip_ctx *ctx, CommitArgs a, uint32_t grid, hipStream_t st) {
     const CommitGeom g = commit_geom(a.cw, a.row_len);
     a.nact = a.cw / g.e < g.threads ? a.cw / g.e : g.threads;
+    if (HASH && a.need) {  // opening hint: only the two big geometries have a masked variant (commit_supports_hint)
+        if (g.e == 16) return launch_commit16<HASH, HASH>(ctx, a, grid, st);
+        if (g.e == 8) return launch_commit<8, HASH, HASH>(ctx, a, g.threads, grid, st);
+        a.need = nullptr;
+    }
     switch (g.e) {
         case 16: return launch_commit16<HASH>(ctx, a, grid, st);
         case 8: return launch_commit<8, HASH>(ctx, a, g.threads, grid, st);
@@ -756,10 +780,25 @@ struct CombineOut {
     uint8_t *row_be = nullptr;      // device
 };
 
+// The per-chunk partial sums of one combination.  Scratch's invariant is "every consumer is enqueued on
+// ctx->stream"; a combination launched on ANOTHER stream (zip_open's `tail` placement on s_aux) therefore
+// keeps its blocks in a CombineScratch of the caller's scope, whose destructor first waits for that stream --
+// on the early error returns too -- before the blocks go back to the pool.
+struct CombineScratch {
+    zip_ctx *ctx;
+    hipStream_t drain = nullptr;  // stream the kernels using the blocks were enqueued on, if not ctx->stream
+    Scratch pint, pa, pb;
+    explicit CombineScratch(zip_ctx *c) : ctx(c), pint(c), pa(c), pb(c) {}
+    ~CombineScratch() {
+        if (drain) (void)hipStreamSynchronize(drain);
+    }
+};
+
 // coeffs_d / q0_d: DEVICE pointers (already staged)
 template <int FL>
 int32_t run_combine_fl(zip_ctx *ctx, hipStream_t st, const int64_t *evals_d, const int64_t *coeffs_dv,
-                       const uint64_t *q0_dv, const HostField *hf, bool do_int, bool do_field, const CombineOut &out) {
+                       const uint64_t *q0_dv, const HostField *hf, bool do_int, bool do_field, const CombineOut &out,
+                       CombineScratch *ext) {
     const uint32_t R = ctx->rows_local, C = ctx->p.row_len;
     const uint32_t bx = (C + 255) / 256;
     // row chunks: enough workgroups to fill the chip, but few enough that the (latency-bound) fold of
@@ -771,7 +810,10 @@ int32_t run_combine_fl(zip_ctx *ctx, hipStream_t st, const int64_t *evals_d, con
     const uint32_t rpc = (R + chunks - 1) / chunks;
     chunks = (R + rpc - 1) / rpc;
 
-    Scratch pint(ctx), pa(ctx), pb(ctx);
+    CombineScratch own(ctx);
+    CombineScratch &cs = ext ? *ext : own;
+    if (st != ctx->stream) cs.drain = st;
+    Scratch &pint = cs.pint, &pa = cs.pa, &pb = cs.pb;
     int32_t rc;
     CombineArgs a{};
     a.evals = evals_d;
@@ -830,13 +872,13 @@ int32_t run_combine_fl(zip_ctx *ctx, hipStream_t st, const int64_t *evals_d, con
 
 int32_t run_combine(zip_ctx *ctx, const int64_t *evals_d, const int64_t *coeffs_dv, const uint64_t *q0_dv,
                     const HostField *hf, bool do_int, bool do_field, const CombineOut &out,
-                    hipStream_t st = nullptr) {
+                    hipStream_t st = nullptr, CombineScratch *ext = nullptr) {
     if (!st) st = ctx->stream;
     const uint32_t fl = hf ? hf->fl : 4;
     switch (fl) {
-        case 2: return run_combine_fl<2>(ctx, st, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out);
-        case 3: return run_combine_fl<3>(ctx, st, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out);
-        default: return run_combine_fl<4>(ctx, st, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out);
+        case 2: return run_combine_fl<2>(ctx, st, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out, ext);
+        case 3: return run_combine_fl<3>(ctx, st, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out, ext);
+        default: return run_combine_fl<4>(ctx, st, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out, ext);
     }
 }
 
@@ -980,12 +1022,7 @@ int32_t launch_encode_row(zip_ctx *ctx, const uint64_t *in, uint64_t *tmp, uint6
     const uint32_t threads = cw < 1024 ? (cw < 64 ? 64 : cw) : 1024;
     const size_t lds = (size_t)threads * sizeof(EncElem<L, FIELD>);
     auto kern = encode_row_kernel<L, FIELD>;
-    static size_t lds_attr = 0;
-    if (lds > lds_attr) {
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_attr = lds;
-    }
+    if (int32_t rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
     LaunchTimer t(ctx, "encode_row_kernel");
     hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, ctx->stream, in, ctx->p.row_len, cw, ctx->perm1_d,
                        ctx->perm2_d, tmp, out, fd, overflow);
@@ -1455,6 +1492,7 @@ void zip_ctx_destroy(zip_ctx *ctx) {
     if (ctx->s_upper) (void)hipStreamDestroy(ctx->s_upper);
     if (ctx->s_aux) (void)hipStreamDestroy(ctx->s_aux);
     if (ctx->stage_big) (void)hipHostFree(ctx->stage_big);
+    for (auto *h : ctx->hint_free) (void)hipHostFree(h);
     if (ctx->pinned_base) (void)hipHostFree(ctx->pinned_base);
     if (ctx->recycle && ctx->bounce[0] && ctx->bounce[1] && ctx->device >= 0 && ctx->device < kMaxDevices) {
         RecycleBin &bin = g_recycle[ctx->device];
@@ -1489,8 +1527,9 @@ int32_t zip_ctx_synchronize(zip_ctx *ctx) {
 
 void *zip_ctx_stream(zip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
-int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
-                   int32_t with_merkle, uint8_t *roots_out, zip_commitment **out) {
+static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
+                           int32_t with_merkle, const uint32_t *hint_cols, uint32_t n_hint, uint8_t *roots_out,
+                           zip_commitment **out) {
     if (!ctx || !out) return ZIP_ERR_NULL;
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1556,6 +1595,37 @@ int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_k
         a.rounds_per_chunk = rpc;
         a.roots = c->roots;
         hipError_t e = hipSuccess;
+        if (with_merkle && hint_cols && commit_supports_hint(cw)) {
+            // the hint bitmaps (CommitArgs.need): V | N0 | N1 | N2, see kernels_commit.cuh
+            const uint32_t wv = (cw + 31) / 32, w1 = (cw / 2 + 31) / 32, w2 = (cw / 4 + 31) / 32;
+            const size_t words = 2 * (size_t)wv + w1 + w2;
+            if (words * 4 > kHintBytes) { rc = fail(ctx, ZIP_ERR_UNSUPPORTED, "hint bitmaps exceed their staging block"); break; }
+            if (!ctx->hint_free.empty()) {
+                c->hint_h = ctx->hint_free.back();
+                ctx->hint_free.pop_back();
+            } else if (hipHostMalloc((void **)&c->hint_h, kHintBytes, hipHostMallocDefault) != hipSuccess) {
+                c->hint_h = nullptr;
+                rc = fail(ctx, ZIP_ERR_ALLOC, "hipHostMalloc(%zu) failed", kHintBytes);
+                break;
+            }
+            uint32_t *bm = reinterpret_cast<uint32_t *>(c->hint_h);
+            memset(bm, 0, words * 4);
+            uint32_t *nv = bm, *n0 = nv + wv, *n1 = n0 + wv, *n2 = n1 + w1;
+            for (uint32_t i = 0; i < n_hint; i++) {
+                const uint32_t col = hint_cols[i];
+                nv[col >> 5] |= 1u << (col & 31);
+                const uint32_t s0 = col ^ 1u, s1 = (col >> 1) ^ 1u, s2 = (col >> 2) ^ 1u;
+                n0[s0 >> 5] |= 1u << (s0 & 31);
+                n1[s1 >> 5] |= 1u << (s1 & 31);
+                n2[s2 >> 5] |= 1u << (s2 & 31);
+            }
+            c->hint_cols.assign(nv, nv + wv);
+            if ((rc = pool_alloc(ctx, kHintBytes, (void **)&c->need_d))) break;
+            e = hipMemcpyAsync(c->need_d, bm, words * 4, hipMemcpyHostToDevice, ctx->s_commit);
+            if (e != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "hint upload failed: %s", hipGetErrorString(e)); break; }
+            a.need = c->need_d;
+            c->hinted = true;
+        }
         if (with_merkle && nch > 1) {
             if ((rc = pool_alloc(ctx, (size_t)nch * 4, (void **)&c->chunk_done))) break;
             e = hipMemsetAsync(c->chunk_done, 0, (size_t)nch * 4, ctx->s_commit);
@@ -1568,6 +1638,9 @@ int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_k
         if (e != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "commit setup failed: %s", hipGetErrorString(e)); break; }
         rc = with_merkle ? dispatch_commit<true>(ctx, a, G, ctx->s_commit) : dispatch_commit<false>(ctx, a, G, ctx->s_commit);
         if (rc) break;
+        c->args = a;
+        c->grid = G;
+        c->evals_ref = evals_d;
         c->done = take_dep_event(ctx);
         e = hipEventRecord(c->done, ctx->s_commit);
         if (e != hipSuccess) rc = fail(ctx, ZIP_ERR_HIP, "commit pipeline failed: %s", hipGetErrorString(e));
@@ -1589,6 +1662,52 @@ int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_k
     return ZIP_OK;
 }
 
+int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
+                   int32_t with_merkle, uint8_t *roots_out, zip_commitment **out) {
+    return commit_impl(ctx, evals, n_evals, evals_kind, with_merkle, nullptr, 0, roots_out, out);
+}
+
+int32_t zip_commit_hinted(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
+                          const uint32_t *cols, uint32_t n_cols, uint8_t *roots_out, zip_commitment **out) {
+    if (!ctx || !out) return ZIP_ERR_NULL;
+    if (n_cols && !cols) return ZIP_ERR_NULL;
+    {
+        std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
+        if (int32_t rc = check_cols(ctx, cols, n_cols)) return rc;
+    }
+    static const uint32_t none = 0;
+    return commit_impl(ctx, evals, n_evals, evals_kind, 1, cols ? cols : &none, n_cols, roots_out, out);
+}
+
+// A hinted commitment is asked for something its kernel did not store: run the commit again, in full, into the
+// same buffers (same witness, same tables: the same bits where they already exist), and wait for it.
+static int32_t rematerialize(zip_commitment *c) {
+    if (!c->hinted) return ZIP_OK;
+    zip_ctx *ctx = c->ctx;
+    CommitArgs a = c->args;
+    a.need = nullptr;
+    a.chunk_done = nullptr;  // the chunks of the first run stay published
+    a.evals = c->evals ? c->evals : c->evals_ref;
+    if (c->done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_commit, c->done, 0));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // nobody still gathers from the buffers
+    int32_t rc = dispatch_commit<true>(ctx, a, c->grid, ctx->s_commit);
+    if (rc) return rc;
+    if (c->done) HIP_TRY(ctx, hipEventRecord(c->done, ctx->s_commit));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_commit));
+    c->hinted = false;
+    return ZIP_OK;
+}
+
+// every column of cols[] lies inside the hint (host check); otherwise the handle is completed first
+static int32_t ensure_columns(zip_commitment *c, const uint32_t *cols, uint32_t n_cols) {
+    if (!c->hinted) return ZIP_OK;
+    for (uint32_t i = 0; i < n_cols; i++) {
+        const uint32_t col = cols[i];
+        if ((col >> 5) >= c->hint_cols.size() || !((c->hint_cols[col >> 5] >> (col & 31)) & 1u)) return rematerialize(c);
+    }
+    return ZIP_OK;
+}
+
 void zip_commitment_free(zip_commitment *c) {
     if (!c) return;
     std::lock_guard<std::recursive_mutex> api_lock(c->ctx->api_mu);
@@ -1601,6 +1720,8 @@ void zip_commitment_free(zip_commitment *c) {
     for (hipEvent_t e : c->aux) c->ctx->dep_event_pool.push_back(e);
     if (c->ctx->stream) (void)hipStreamSynchronize(c->ctx->stream);
     pool_release(c->ctx, c->chunk_done);
+    pool_release(c->ctx, c->need_d);
+    if (c->hint_h) c->ctx->hint_free.push_back(c->hint_h);
     pool_release(c->ctx, c->rows);
     pool_release(c->ctx, c->layers);
     pool_release(c->ctx, c->roots);
@@ -1614,8 +1735,9 @@ int32_t zip_commitment_device_ptrs(zip_commitment *c, uint64_t **rows, uint8_t *
     if (!c) return ZIP_ERR_NULL;
     std::lock_guard<std::recursive_mutex> api_lock(c->ctx->api_mu);
     // work enqueued on the ctx stream (zip_ctx_stream) after this call sees complete data
-    int32_t rc_ = wait_ready(c, c->ctx->stream);
+    int32_t rc_ = (rows || layers) ? rematerialize(c) : ZIP_OK;
     if (rc_) return rc_;
+    if ((rc_ = wait_ready(c, c->ctx->stream))) return rc_;
     if (rows) {
         if ((rc_ = materialize_rows(c))) return rc_;
         *rows = c->rows;
@@ -1638,8 +1760,13 @@ static int32_t materialize_rows(zip_commitment *c) {
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 65535);
     hipLaunchKernelGGL(expand_rows_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(c->rows),
                        static_cast<uint4 *>(full), n);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->stream);  // nothing may still write `full` when it returns to the pool
+        pool_release(ctx, full);
+        return fail(ctx, ZIP_ERR_HIP, "expanding the row entries failed: %s", hipGetErrorString(e));
+    }
     pool_release(ctx, c->rows);
     c->rows = static_cast<uint64_t *>(full);
     c->rows_bytes = (size_t)n * 32;
@@ -1654,8 +1781,9 @@ int32_t zip_commit_download(zip_commitment *c, uint64_t *rows_out, uint8_t *laye
     std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
     const uint32_t R = ctx->rows_local, cw = ctx->p.codeword_len;
     {
-        int32_t rc_ = wait_ready(c, ctx->stream);
+        int32_t rc_ = (rows_out || layers_out) ? rematerialize(c) : ZIP_OK;
         if (rc_) return rc_;
+        if ((rc_ = wait_ready(c, ctx->stream))) return rc_;
     }
     if (rows_out) {
         int32_t rc_ = materialize_rows(c);
@@ -1766,6 +1894,7 @@ int32_t zip_open_columns(zip_commitment *c, const uint32_t *cols, uint32_t n_col
         out_d = res.as<uint8_t>();
     }
     if ((rc = check_cols(ctx, cols, n_cols))) return rc;
+    if ((rc = ensure_columns(c, cols, n_cols))) return rc;
     Scratch small(ctx);
     SmallInputs si;
     si.src[0] = cols;
@@ -1857,7 +1986,11 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
     o.uprime = single ? nullptr : reinterpret_cast<uint64_t *>(out_d);
     o.row_be = out_d + u_bytes + col_bytes;
     if ((rc = check_cols(ctx, cols, n_cols))) return rc;
+    if ((rc = ensure_columns(c, cols, n_cols))) return rc;
     Scratch small(ctx);
+    // declared last = destroyed first: on every return path the combination enqueued on s_aux has drained before
+    // `small`, `ev` and `res` (its inputs and output) and its own partial sums go back to the pool
+    CombineScratch cscr(ctx);
     SmallInputs si;
     if (!single) {
         si.src[0] = coeffs;
@@ -1893,7 +2026,7 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
         // tail: held back until the commit kernel has ended, so that it runs beside the gather of the LAST
         // chunk (memory-bound, nothing left to hash) instead of beside the commit
         if (place == 3 && c->done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, c->done, 0));
-        if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o, ctx->s_aux))) return rc;
+        if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o, ctx->s_aux, &cscr))) return rc;
         HIP_TRY(ctx, hipEventRecord(combined, ctx->s_aux));
     }
     if ((rc = run_open_columns_pipelined(c, reinterpret_cast<const uint32_t *>(sb + si.off[2]), n_cols,
@@ -2083,6 +2216,7 @@ int32_t zip_open_stream(zip_commitment *c, const int64_t *evals, zip_mem_kind ev
     const bool single = ctx->p.num_rows == 1;
     if (!single && (!coeffs || !q0_mont)) return fail(ctx, ZIP_ERR_NULL, "coeffs / q0_mont is NULL");
     if ((rc = check_cols(ctx, cols, n_cols))) return rc;
+    if ((rc = ensure_columns(c, cols, n_cols))) return rc;
     Scratch ev(ctx), ends(ctx), small(ctx), dev0(ctx), dev1(ctx);
     const int64_t *evals_d = c->evals;
     if (evals) {

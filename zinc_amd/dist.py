@@ -57,7 +57,7 @@ class HipBackend:
 
     def commit(self, evals):
         com, _ = self.ctx.commit(evals, want_roots=False)
-        _, _, roots_ptr = com.device_ptrs()
+        roots_ptr = com.roots_ptr()
         self.ctx.synchronize()
         holder = type("_H", (), {})()
         holder.__cuda_array_interface__ = {"shape": (self.ctx.rows_local, 32), "typestr": "|u1",
