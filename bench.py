@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--num-vars", type=int, default=24)
     ap.add_argument("--shard", choices=["polys", "rows"], default="polys")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hint", action="store_true",
+                    help="plain zip_commit (every row entry and tree node stored) instead of zip_commit_hinted")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5A494E43)
     args = ap.parse_args()
 
@@ -205,7 +207,9 @@ def main():
             com, _roots = sharded.commit(evals_d)
             sharded.open(com, evals_d, coeffs, cols, q0, zf)
         else:
-            com, _ = ctx.commit(evals_d, want_roots=False)  # asynchronous: the open below overlaps it
+            # asynchronous: the open below overlaps it.  The columns are known before the commit, as in the prover
+            # flow (fresh PcsTranscript, src/zinc/prover.rs:316): the commit kernel skips the stores they never read
+            com, _ = ctx.commit(evals_d, want_roots=False, hint_cols=None if args.no_hint else cols)
             com.open(evals_d, coeffs, cols, q0, zf, out=proof)  # returns when the whole stream is in HBM
             if world > 1:
                 # the one exchange of the commit: every rank's Merkle roots

@@ -1,9 +1,12 @@
 #!/bin/bash
-# A/B of environment knobs on the default bench (GPU box): edit the `run` lines, then
-#   gpurun -- 'bash tools/exp.sh > gpurun_out/exp.log 2>&1; cat gpurun_out/exp.log'
-# Box-to-box and run-to-run noise is 3-5 %: alternate the variants and repeat.
-run() { echo -n "$* : "; env "$@" timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline $EXTRA 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k:v for k,v in d['kernels_ms_per_step'].items() if 'wait' not in k})"; }
-for i in 1 2 3 4; do
-run ZIP_HIP_NO_COMPACT_ROWS=1
-run ZIP_HIP_X=compact
+run() { local flags="$1"; shift; echo -n "[$flags] $* : "; env "$@" timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline $flags 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k:v for k,v in d['kernels_ms_per_step'].items() if 'wait' not in k})"; }
+for i in 1 2; do
+run "" ZIP_HIP_COMBINE=tail
+run "" X=1
+run "" ZIP_HIP_CHUNK_ROUNDS=5,5,4,1,1
+run "" ZIP_HIP_CHUNK_ROUNDS=6,5,3,1,1
+run "" ZIP_HIP_CHUNK_ROUNDS=4,4,4,2,1,1
+run "" ZIP_HIP_CHUNK_ROUNDS=5,4,4,2,1
+run "" ZIP_HIP_CHUNK_ROUNDS=4,4,4,3,1
+run "" ZIP_HIP_COMBINE=aux
 done

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--num-vars", type=int, default=24)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--serial", action="store_true", help="wait for the commit before opening (kernels timed alone)")
+    ap.add_argument("--hint", action="store_true", help="zip_commit_hinted with the columns of the open")
     args = ap.parse_args()
     import torch
 
@@ -31,7 +32,7 @@ def main():
     for rep in range(args.reps + 1):
         if rep == 1:
             ctx.set_profiling(True)
-        com, _ = ctx.commit(evals, want_roots=False)
+        com, _ = ctx.commit(evals, want_roots=False, hint_cols=cols if args.hint else None)
         if args.serial:
             ctx.synchronize()
         com.open(evals, coeffs, cols, q0, zf, out=proof)

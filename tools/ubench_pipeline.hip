@@ -26,8 +26,10 @@ __global__ void __launch_bounds__(256) gather_stream(const uint4 *in, uint4 *out
 }
 __global__ void stamp_kernel(unsigned long long *out) { if (threadIdx.x == 0) *out = wall_clock64(); }
 
-int main() {
-    const uint32_t R = 4096, C = 4096, cw = 8192, G = 256, nch = 8, rpc = 2;
+int main(int argc, char **argv) {
+    const uint32_t R = 4096, C = 4096, cw = 8192, G = 256;
+    const uint32_t rpc = argc > 1 ? (uint32_t)atoi(argv[1]) : 4;  // rounds per chunk
+    const int modes = argc > 2 ? atoi(argv[2]) : 4;
     std::vector<uint32_t> p1(cw), p2(cw);
     std::iota(p1.begin(), p1.end(), 0); std::iota(p2.begin(), p2.end(), 0);
     std::mt19937 g(1); std::shuffle(p1.begin(), p1.end(), g); std::shuffle(p2.begin(), p2.end(), g);
@@ -50,7 +52,8 @@ int main() {
     hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const char *names[] = {"alone", "+copy 512 blocks x 6 GiB", "+gather 512 blocks", "+gather 2048 blocks"};
-    for (int mode = 0; mode < 4; mode++) {
+    printf("rounds per chunk %u\n", rpc);
+    for (int mode = 0; mode < modes; mode++) {
         float ms = 0;
         for (int rep = 0; rep < 2; rep++) {
             CK(hipMemset(a.chunk_done, 0, 256)); CK(hipDeviceSynchronize());

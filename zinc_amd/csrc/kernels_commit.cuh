@@ -36,7 +36,8 @@ struct CommitArgs {
     uint32_t cw;
     uint32_t nact;  // active threads per workgroup = cw / E
     uint32_t num_rows;          // rows of this ctx (the kernel is persistent: row = blockIdx.x + i * gridDim.x)
-    uint32_t rounds_per_chunk;  // a chunk = this many consecutive rounds of gridDim.x rows
+    uint32_t rounds_per_chunk;  // a chunk = this many consecutive rounds of gridDim.x rows ...
+    uint64_t chunk_ends;        // ... or, when non-zero, bit r set = a chunk ends with round r (unequal chunks, <= 64 rounds)
     uint32_t *chunk_done;       // [chunks] arrival counters, or null
     // Opening hint (zip_commit_hinted): bitmaps of what an open of the hinted columns will ever read, or null =
     // store everything.  Words: [V: cw bits, entry j is opened][N0: cw bits][N1: cw/2][N2: cw/4], N_l bit i = node i
@@ -252,12 +253,26 @@ __device__ __forceinline__ void bfly_hash(Src &src, uint32_t (&h)[8]) {
 // paid once per chunk, not per row), the roots, then the publication of the chunk.  The children of
 // the first level were stored by this workgroup: a barrier makes them visible (one CU, one L1; the
 // lines were never read before they were written).
+// The chunk schedule of a persistent commit kernel, tracked per workgroup in scalar registers.
+struct ChunkCursor {
+    uint32_t first = 0, index = 0;  // first round and number of the chunk in progress
+    __device__ __forceinline__ bool ends_with(const CommitArgs &a, uint32_t round, bool last) const {
+        if (last) return true;
+        if (a.chunk_ends) return (a.chunk_ends >> round) & 1u;
+        return (round + 1) % a.rounds_per_chunk == 0;
+    }
+    __device__ __forceinline__ void advance(uint32_t round) {
+        first = round + 1;
+        index++;
+    }
+};
+
 template <bool HASH>
-__device__ __forceinline__ void finish_chunk(const CommitArgs &a, uint32_t first_level, uint32_t round, uint32_t tid,
-                                             uint32_t T) {
+__device__ __forceinline__ void finish_chunk(const CommitArgs &a, uint32_t first_level, const ChunkCursor &cc,
+                                             uint32_t round, uint32_t tid, uint32_t T) {
     const uint32_t cw = a.cw;
     if (HASH) {
-        const uint32_t first = (round / a.rounds_per_chunk) * a.rounds_per_chunk;
+        const uint32_t first = cc.first;
         const uint32_t nrows_c = round - first + 1;
         const uint32_t depth = 31u - __builtin_clz(cw);
         __syncthreads();
@@ -292,10 +307,9 @@ __device__ __forceinline__ void finish_chunk(const CommitArgs &a, uint32_t first
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back has landed before the count moves
-            __hip_atomic_fetch_add(&a.chunk_done[round / a.rounds_per_chunk], 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&a.chunk_done[cc.index], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef ZIPK_DEBUG_STAMPS
-            a.stamps[(round / a.rounds_per_chunk) * gridDim.x + blockIdx.x] = wall_clock64();
+            a.stamps[cc.index * gridDim.x + blockIdx.x] = wall_clock64();
 #endif
         }
     }
@@ -381,6 +395,7 @@ __global__ void __launch_bounds__(1024, MASKED ? 4 : 5) raa_commit_kernel(Commit
 #define ZIPK_PH(acc) do { } while (0)
 #endif
     uint32_t round = 0;
+    ChunkCursor cc;
     for (uint32_t row = blockIdx.x; row < a.num_rows; row += gridDim.x, round++) {
 #ifdef ZIPK_DEBUG_STAMPS
         ph_t = wall_clock64();
@@ -491,8 +506,9 @@ __global__ void __launch_bounds__(1024, MASKED ? 4 : 5) raa_commit_kernel(Commit
         ZIPK_PH(ph_b);
         // ---- finish a chunk: upper Merkle levels of this workgroup's rows, then publish ------
         const bool last = row + gridDim.x >= a.num_rows;
-        if (last || (round + 1) % a.rounds_per_chunk == 0) {
-            finish_chunk<HASH>(a, LOGE + 1, round, tid, T);
+        if (cc.ends_with(a, round, last)) {
+            finish_chunk<HASH>(a, LOGE + 1, cc, round, tid, T);
+            cc.advance(round);
         }
         ZIPK_PH(ph_c);
     }
@@ -572,6 +588,7 @@ __global__ void __launch_bounds__(1024, 4) raa_commit16_kernel(CommitArgs a) {
     const uint32_t smask1 = MASKED ? store_mask<8>(a.need, cw, 0u, 16u, (tid0 & ~7u) * 16u + 8u + (tid0 & 7u)) : 0xFFFFFFFFu;
 
     uint32_t round = 0;
+    ChunkCursor cc;
     for (uint32_t row = blockIdx.x; row < a.num_rows; row += gridDim.x, round++) {
         const uint32_t z = opaque_zero(row);
         const uint32_t tid = tid0 + z;
@@ -685,7 +702,10 @@ __global__ void __launch_bounds__(1024, 4) raa_commit16_kernel(CommitArgs a) {
             }
         }
         const bool last = row + gridDim.x >= a.num_rows;
-        if (last || (round + 1) % a.rounds_per_chunk == 0) finish_chunk<HASH>(a, 4u, round, tid, T);
+        if (cc.ends_with(a, round, last)) {
+            finish_chunk<HASH>(a, 4u, cc, round, tid, T);
+            cc.advance(round);
+        }
     }
 }
 

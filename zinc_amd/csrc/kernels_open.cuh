@@ -132,6 +132,7 @@ struct CombineArgs {
     const int64_t *coeffs;  // [num_rows]            (device)
     const uint64_t *q0;     // [num_rows][FL]        (device, Montgomery limbs)
     uint32_t num_rows, row_len, rows_per_chunk;
+    uint32_t prio;  // s_setprio level: the kernel usually runs beside the (older, always ready) hashing waves of the commit
     uint64_t quirk_mod;
     uint64_t *part_int;  // [chunks][row_len][3]
     uint64_t *part_a;    // [chunks][row_len][FL+2]
@@ -140,6 +141,7 @@ struct CombineArgs {
 
 template <int FL, bool DO_INT, bool DO_FIELD>
 __global__ void __launch_bounds__(256) combine_rows_kernel(CombineArgs a) {
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= a.row_len) return;
     const uint32_t chunk = blockIdx.y;
@@ -209,21 +211,28 @@ __global__ void __launch_bounds__(256) combine_rows_kernel(CombineArgs a) {
 struct FinalizeArgs {
     const uint64_t *part_int, *part_a, *part_b;
     uint32_t chunks, row_len, m_limbs;
+    uint32_t prio;        // s_setprio level (see CombineArgs)
     uint64_t *uprime;     // [row_len][m_limbs] little-endian limbs, or null
     uint64_t *row_limbs;  // [row_len][FL] Montgomery little-endian limbs, or null
     uint8_t *row_be;      // [row_len][8*FL] big-endian bytes of the Montgomery value, or null
 };
 
-// 32 columns per workgroup, eight threads per column: each sums every eighth chunk (the fold is latency-bound --
+// 16 columns per workgroup, eight threads per column: each sums every eighth chunk (the fold is latency-bound --
 // one thread per column walking all chunks left 16 waves on the whole chip waiting on one load after another),
 // then the eight partial sums meet in LDS and the first thread of the column finishes.
-constexpr uint32_t kFinalizeCols = 32, kFinalizeGroups = 8;
+// 16 columns = 15 KB of LDS: the kernel must fit into the 29 KB the persistent commit workgroups leave free on a
+// CU, or it only starts when they end (32 columns = 30.7 KB waited 1.2 ms for exactly that).
+constexpr uint32_t kFinalizeCols = 16, kFinalizeGroups = 8;
 
 template <int FL, bool DO_INT, bool DO_FIELD>
-__global__ void __launch_bounds__(256) combine_finalize_kernel(FinalizeArgs a, FieldDev<FL> f) {
+// (capped at 88 VGPRs, so that a wave fits into the 96 registers per lane the
+// hinted commit kernel leaves free on every SIMD; at its natural 126 the kernel waited for the commit to end)
+__global__ void __launch_bounds__(kFinalizeCols * kFinalizeGroups) __attribute__((amdgpu_num_vgpr(88)))
+combine_finalize_kernel(FinalizeArgs a, FieldDev<FL> f) {
     __shared__ uint64_t sh_int[kFinalizeGroups][kFinalizeCols][3];
     __shared__ uint64_t sh_a[kFinalizeGroups][kFinalizeCols][FL + 2];
     __shared__ uint64_t sh_b[kFinalizeGroups][kFinalizeCols][FL + 2];
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t lc = threadIdx.x % kFinalizeCols, g = threadIdx.x / kFinalizeCols;
     const uint32_t col = blockIdx.x * kFinalizeCols + lc;
     const bool valid = col < a.row_len;

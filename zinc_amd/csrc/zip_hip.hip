@@ -798,7 +798,9 @@ struct CombineScratch {
 template <int FL>
 int32_t run_combine_fl(zip_ctx *ctx, hipStream_t st, const int64_t *evals_d, const int64_t *coeffs_dv,
                        const uint64_t *q0_dv, const HostField *hf, bool do_int, bool do_field, const CombineOut &out,
-                       CombineScratch *ext) {
+                       CombineScratch *ext, int phase) {
+    // phase 0: both kernels; 1: only the pass over the witness (partial sums into `ext`); 2: only the fold of the
+    // partial sums `ext` already holds.  zip_open runs them at the two ends of its pipeline.
     const uint32_t R = ctx->rows_local, C = ctx->p.row_len;
     const uint32_t bx = (C + 255) / 256;
     // row chunks: enough workgroups to fill the chip, but few enough that the (latency-bound) fold of
@@ -820,20 +822,22 @@ int32_t run_combine_fl(zip_ctx *ctx, hipStream_t st, const int64_t *evals_d, con
     a.num_rows = R;
     a.row_len = C;
     a.rows_per_chunk = rpc;
+    static const int combine_prio = getenv("ZIP_HIP_COMBINE_PRIO") ? atoi(getenv("ZIP_HIP_COMBINE_PRIO")) : 1;
+    a.prio = (uint32_t)combine_prio;
     a.quirk_mod = hf ? hf->quirk_mod : 0;
     if (do_int) {
-        if ((rc = pint.get((size_t)chunks * C * 3 * 8))) return rc;
+        if (phase != 2 && (rc = pint.get((size_t)chunks * C * 3 * 8))) return rc;
         a.coeffs = coeffs_dv;
         a.part_int = pint.as<uint64_t>();
     }
     if (do_field) {
-        if ((rc = pa.get((size_t)chunks * C * (FL + 2) * 8))) return rc;
-        if ((rc = pb.get((size_t)chunks * C * (FL + 1) * 8))) return rc;
+        if (phase != 2 && (rc = pa.get((size_t)chunks * C * (FL + 2) * 8))) return rc;
+        if (phase != 2 && (rc = pb.get((size_t)chunks * C * (FL + 1) * 8))) return rc;
         a.q0 = q0_dv;
         a.part_a = pa.as<uint64_t>();
         a.part_b = pb.as<uint64_t>();
     }
-    {
+    if (phase != 2) {
         LaunchTimer t(ctx, "combine_rows_kernel", st);
         const dim3 grid(bx, chunks), block(256);
         if (do_int && do_field)
@@ -851,12 +855,13 @@ int32_t run_combine_fl(zip_ctx *ctx, hipStream_t st, const int64_t *evals_d, con
     fa.chunks = chunks;
     fa.row_len = C;
     fa.m_limbs = ctx->p.m_limbs;
+    fa.prio = a.prio;
     fa.uprime = out.uprime;
     fa.row_limbs = out.row_limbs;
     fa.row_be = out.row_be;
     FieldDev<FL> fd{};
     if (hf) fd = to_dev<FL>(*hf);
-    {
+    if (phase != 1) {
         LaunchTimer t(ctx, "combine_finalize_kernel", st);
         const dim3 grid((C + kFinalizeCols - 1) / kFinalizeCols), block(kFinalizeCols * kFinalizeGroups);
         if (do_int && do_field)
@@ -872,13 +877,13 @@ int32_t run_combine_fl(zip_ctx *ctx, hipStream_t st, const int64_t *evals_d, con
 
 int32_t run_combine(zip_ctx *ctx, const int64_t *evals_d, const int64_t *coeffs_dv, const uint64_t *q0_dv,
                     const HostField *hf, bool do_int, bool do_field, const CombineOut &out,
-                    hipStream_t st = nullptr, CombineScratch *ext = nullptr) {
+                    hipStream_t st = nullptr, CombineScratch *ext = nullptr, int phase = 0) {
     if (!st) st = ctx->stream;
     const uint32_t fl = hf ? hf->fl : 4;
     switch (fl) {
-        case 2: return run_combine_fl<2>(ctx, st, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out, ext);
-        case 3: return run_combine_fl<3>(ctx, st, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out, ext);
-        default: return run_combine_fl<4>(ctx, st, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out, ext);
+        case 2: return run_combine_fl<2>(ctx, st, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out, ext, phase);
+        case 3: return run_combine_fl<3>(ctx, st, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out, ext, phase);
+        default: return run_combine_fl<4>(ctx, st, evals_d, coeffs_dv, q0_dv, hf, do_int, do_field, out, ext, phase);
     }
 }
 
@@ -1577,10 +1582,46 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
         if (nch > rounds) nch = rounds;
         const uint32_t rpc = (rounds + nch - 1) / nch;
         nch = (rounds + rpc - 1) / rpc;
+        // chunk schedule in rounds: equal chunks, or (ZIP_HIP_CHUNK_ROUNDS="8,4,2,1,1", <= 64 rounds) an explicit one
+        // whose last entry is stretched / cut to the number of rounds
+        std::vector<uint32_t> sched;
+        if (with_merkle && rounds <= 64) {
+            static const char *env = getenv("ZIP_HIP_CHUNK_ROUNDS");
+            if (env && !ctx->n_chunks) {
+                uint32_t used = 0;
+                for (const char *q = env; *q && used < rounds;) {
+                    char *endp = nullptr;
+                    const long v = strtol(q, &endp, 10);
+                    if (endp == q) break;
+                    if (v >= 1) {
+                        const uint32_t take = std::min<uint32_t>((uint32_t)v, rounds - used);
+                        sched.push_back(take);
+                        used += take;
+                    }
+                    q = (*endp == ',') ? endp + 1 : endp;
+                }
+                if (!sched.empty() && used < rounds) sched.back() += rounds - used;
+            }
+        }
+        uint64_t chunk_ends = 0;
+        if (sched.empty()) {
+            for (uint32_t k = 0; k < nch; k++) sched.push_back(std::min(rpc, rounds - k * rpc));
+        } else {
+            nch = (uint32_t)sched.size();
+            uint32_t r = 0;
+            for (uint32_t k = 0; k < nch; k++) {
+                r += sched[k];
+                chunk_ends |= 1ull << (r - 1);
+            }
+        }
         c->bounds.resize(nch + 1);
-        for (uint32_t k = 0; k <= nch; k++) {
-            const uint64_t b = (uint64_t)k * rpc * G;
-            c->bounds[k] = b < R ? (uint32_t)b : R;
+        {
+            uint64_t r = 0;
+            for (uint32_t k = 0; k <= nch; k++) {
+                const uint64_t b = r * G;
+                c->bounds[k] = b < R ? (uint32_t)b : R;
+                if (k < nch) r += sched[k];
+            }
         }
         CommitArgs a{};
         a.evals = evals_d;
@@ -1593,6 +1634,7 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
         a.cw = cw;
         a.num_rows = R;
         a.rounds_per_chunk = rpc;
+        a.chunk_ends = chunk_ends;
         a.roots = c->roots;
         hipError_t e = hipSuccess;
         if (with_merkle && hint_cols && commit_supports_hint(cw)) {
@@ -2003,16 +2045,19 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
     unsigned char *sb;
     if ((rc = stage_small(ctx, si, small, &sb))) return rc;
     // The two row combinations do not depend on the commitment.  Where to put them (ZIP_HIP_COMBINE):
-    //   tail (default)  on their own stream, held back until the commit kernel has ended: the multiply-bound
-    //                   kernel then runs beside the gather of the last chunk (memory-bound, nothing left to
-    //                   hash); 2.27 ms per step against 2.33 for `last`, and steadier;
-    //   last            after the gathers, alone: 0.16 ms;
-    //   aux             on their own stream from the start, beside commit and gathers: starved there
-    //                   (1.3-1.6 ms) and slows the others -- 3-5 % worse on the step;
-    //   first           on the main stream ahead of the gathers: they then wait 1.3 ms for it (serial).
+    //   split (default) the pass over the witness FIRST on the main stream -- the stream would otherwise idle until the
+    //                   commit kernel publishes its first chunk, and with s_setprio the pass is not starved by the
+    //                   hashing waves (0.26 ms there; 1.5 ms without the priority) -- and the fold of its partial
+    //                   sums LAST, after the gathers: that kernel needs more VGPRs than the commit kernel leaves
+    //                   free, so anywhere earlier it waits for the commit to end (and the gathers behind it);
+    //   tail            both on their own stream, held back until the commit kernel has ended: beside the gather of
+    //                   the last chunk, where the pass takes 0.3 ms and is the end of the step (round 1's default);
+    //   last            after the gathers, alone;
+    //   aux             on their own stream from the start;
+    //   first           both on the main stream ahead of the gathers.
     static const char *combine_env = getenv("ZIP_HIP_COMBINE");
-    static const int place = !combine_env ? 3 : !strcmp(combine_env, "aux") ? 1 : !strcmp(combine_env, "first") ? 0 :
-                             !strcmp(combine_env, "last") ? 2 : 3;
+    static const int place = !combine_env ? 4 : !strcmp(combine_env, "aux") ? 1 : !strcmp(combine_env, "first") ? 0 :
+                             !strcmp(combine_env, "last") ? 2 : !strcmp(combine_env, "tail") ? 3 : 4;
     const int64_t *coeffs_dv = reinterpret_cast<const int64_t *>(sb + si.off[0]);
     const uint64_t *q0_dv = reinterpret_cast<const uint64_t *>(sb + si.off[1]);
     hipEvent_t staged = take_dep_event(ctx), combined = take_dep_event(ctx);
@@ -2020,6 +2065,8 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
     c->aux.push_back(combined);
     if (place == 0) {
         if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o))) return rc;
+    } else if (place == 4) {
+        if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o, nullptr, &cscr, 1))) return rc;
     } else if (place == 1 || place == 3) {
         HIP_TRY(ctx, hipEventRecord(staged, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, staged, 0));
@@ -2034,6 +2081,8 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
         return rc;
     if (place == 2) {
         if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o))) return rc;
+    } else if (place == 4) {
+        if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o, nullptr, &cscr, 2))) return rc;
     } else if (place == 1 || place == 3) {
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, combined, 0));
     }
