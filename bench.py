@@ -105,19 +105,35 @@ def cpu_baseline(num_vars, seed, budget_s=20.0):
             "sample": f"oracle commit+open of one 2^{nv}-coefficient witness, {dt:.2f} s wall (OpenMP over rows/columns)"}
 
 
-def pmc_traffic(kernel, num_vars):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
-    (profiles/pmc_traffic.json, written by tools/pmc_summary.py from the raw CSVs), or None."""
+def pmc_entry(kernel, num_vars, mode):
+    """Per-launch counters of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by
+    tools/pmc_summary.py from the raw CSVs of tools/profile_round.sh), or None.  Evidence measured once per round on the
+    same code, not in this run (counter collection serialises the streams); `source` names the file."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
             d = json.load(fh)
-        e = d.get(kernel)
-        if e and e.get("num_vars") == num_vars:
-            return int(e["traffic_bytes"])
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+        return d.get(f"{kernel}:{num_vars}:{mode}") or d.get(f"{kernel}:{num_vars}:any")
+    except (OSError, ValueError):
+        return None
+
+
+def commit_moved_bytes(per, row_len, cw, depth, cols):
+    """Bytes the commit kernel really moves per launch (as opposed to SURVEY 8d's full-materialisation figure): the
+    witness, 16-byte row entries (the 96 significant bits + sign; Int<4> only on demand), the tree nodes, the
+    children of levels >= 4 read back by the in-kernel upper levels, the roots.  cols = the opening hint (None: plain
+    commit): then only the entries / leaf hashes / level-1 and -2 nodes an opening of those columns reads are stored."""
+    upper_nodes = max(cw // 4 - 1, 0)  # levels 3 .. depth
+    reread = 2 * 32 * max(cw // 8 - 1, 0)  # children of levels 4 .. depth
+    if cols is None:
+        per_row = 16 * cw + 32 * (2 * cw - 1)
+    else:
+        c = np.unique(np.asarray(cols, dtype=np.int64))
+        n0 = c.size
+        n1 = np.unique((c >> 1) ^ 1).size
+        n2 = np.unique((c >> 2) ^ 1).size
+        per_row = 16 * c.size + 32 * (n0 + n1 + n2 + upper_nodes)
+    return int(per * (row_len * 8 + per_row + reread + 32))
 
 
 def roots_view(torch, ptr, rows, dev):
@@ -235,6 +251,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ktimes = ctx.profile_read()
+    clock_mhz = ctx.commit_clock_mhz()  # shader clock during the last timed commit kernel (in-kernel stamps)
     ctx.set_profiling(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=xdev)
@@ -253,6 +270,22 @@ def main():
         avg_ms = tot_ms / launches
         commit_bytes = per * row_len * 8 + per * cw * 32 * 3
         achieved = commit_bytes / (avg_ms * 1e-3) / 1e9
+        mode = "plain" if args.no_hint else "hinted"
+        moved = commit_moved_bytes(per, row_len, cw, depth, None if args.no_hint else cols)
+        pe = pmc_entry(dom, nv, mode) if not rows_mode else None
+        traffic = int((2 * pe["fetch_kib"] + pe["write_kib"]) * 1024) if pe else None  # reads x2: profiles/*_fetch_calibration.md
+        simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+        valu = None
+        if pe and pe.get("valu_insts") and clock_mhz > 0:
+            peak_ginst = simds * clock_mhz * 1e6 / 4 / 1e9  # one wave64 int32 instruction per 4 cycles per SIMD (tools/ubench_blake3)
+            ach_ginst = pe["valu_insts"] / (avg_ms * 1e-3) / 1e9
+            valu = {"kernel": dom, "insts_per_launch": int(pe["valu_insts"]), "insts_source": pe["source"],
+                    "issue_cycles_per_inst": 4, "simds": simds, "clock_mhz": round(clock_mhz, 1),
+                    "achieved": round(ach_ginst, 1), "peak": round(peak_ginst, 1), "unit": "G wave-inst/s",
+                    "frac": round(ach_ginst / peak_ginst, 4)}
+        gather_bytes = ab["gather"]
+        g_l, g_ms = ktimes.get("open_columns_kernel", (0, 0.0))
+        configs_idx = {24: "configs[2]", 26: "configs[3] geometry, whole polynomial on one GPU", 20: "configs[1] + open"}.get(nv, "non-headline size")
         out = {
             "metric": "Zip commit+open MCoeffs/s at 2^%d witness" % nv,
             "value": round(coeffs_per_step / step_s / 1e6, 2),
@@ -266,16 +299,33 @@ def main():
             "vs_baseline": None,
             "dtype": "i64",
             "data": "synthetic (SplitMix64 full-range i64 witness; coefficient / column / point streams per SURVEY.md 8d)",
-            "config": {"workload": "Zip commit+open_z 2^%d coeffs (BASELINE configs[2])" % nv, "row_len": row_len,
+            "config": {"workload": "Zip commit+open_z 2^%d coeffs (BASELINE %s)" % (nv, configs_idx), "row_len": row_len,
                        "num_rows": num_rows, "codeword_len": cw, "column_openings": n_cols, "field_limbs": fl,
-                       "parallelism": ("rows%d" % world if rows_mode else "polys%d" % world)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                       "parallelism": ("rows%d" % world if rows_mode else "polys%d" % world),
+                       "commit": ("zip_commit (everything stored)" if args.no_hint else
+                                  "zip_commit_hinted (the 1000 columns are known before the commit, prover.rs:316; "
+                                  "stores no opening reads are skipped)")},
+            # the contract's HBM figure for the dominant kernel: SURVEY 8d algorithmic bytes / its launch time / 8 TB/s ...
+            "roofline": {"bound": "valu", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic(dom, nv) if not rows_mode else None,
+                         "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(commit_bytes),
-                         "note": "this kernel is int32-VALU bound, not HBM bound: 67.1M BLAKE3 compressions are "
-                                 "7.7e8 wave-instructions, a 1.35 ms issue floor at the 2.2 GHz the chip holds "
-                                 "(DESIGN.md); the column gather of finished chunks runs beside it, which stretches it from 1.45 ms alone"},
+                         "moved_bytes_per_launch": moved,
+                         "moved_gbs": round(moved / (avg_ms * 1e-3) / 1e9, 1),
+                         "note": "bound = valu: %.1fM BLAKE3 compressions per launch at 680 int32 VALU instructions each; HBM is "
+                                 "not what binds this kernel (roofline_valu).  `achieved` prices SURVEY 8d's full "
+                                 "materialisation (200 B/coeff); `moved_bytes_per_launch` is what this build stores "
+                                 "(16-byte row entries%s); `traffic` = FETCH_SIZE x2 + WRITE_SIZE of the committed PMC pass"
+                                 % (per * (2 * cw - 1) / 1e6, "" if args.no_hint else ", only what the hinted openings read")},
+            # ... and the roofline that does bind it
+            "roofline_valu": valu,
+            "roofline_gather": {"bound": "hbm", "kernel": "open_columns_kernel",
+                                "algorithmic_bytes_per_step": int(gather_bytes),
+                                "sum_ms_per_step": round(g_ms / args.steps, 4),
+                                "achieved": round(gather_bytes / (g_ms / args.steps * 1e-3) / 1e9, 1) if g_ms else None,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(gather_bytes / (g_ms / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if g_ms else None,
+                                "note": "per-chunk launches summed; they run beside the commit kernel"},
             "whole_path": {"algorithmic_bytes": int(sum(ab.values())),
                            "hbm_frac": round(sum(ab.values()) / step_s / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(ktimes.items())},

@@ -341,6 +341,10 @@ typedef struct {
     float total_ms;
 } zip_kernel_time;
 int32_t zip_ctx_set_profiling(zip_ctx *ctx, int32_t on);
+/* Shader clock (MHz) the chip held during the most recent commit kernel launched with profiling on: the kernel's
+ * first workgroup stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) at its start and end.  0 if none.
+ * bench.py prices the VALU roofline of the commit kernel at this clock. */
+int32_t zip_ctx_commit_clock(zip_ctx *ctx, double *mhz_out);
 int32_t zip_ctx_profile_read(zip_ctx *ctx, zip_kernel_time *out, uint32_t cap);
 
 #ifdef __cplusplus

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Per-kernel HIP-event times through the C ABI's measurement hooks (GPU box)."""
+"""Per-kernel HIP-event times through the C ABI's measurement hooks (GPU box).  Also the workload of the PMC passes
+of tools/profile_round.sh: one process runs the hinted AND the plain commit (their kernels are different template
+instances, so rocprofv3 lists them separately) followed by the open."""
 import argparse
 import os
 import sys
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--serial", action="store_true", help="wait for the commit before opening (kernels timed alone)")
     ap.add_argument("--hint", action="store_true", help="zip_commit_hinted with the columns of the open")
+    ap.add_argument("--both", action="store_true", help="alternate hinted and plain commits (PMC passes)")
     args = ap.parse_args()
     import torch
 
@@ -32,17 +33,19 @@ def main():
     for rep in range(args.reps + 1):
         if rep == 1:
             ctx.set_profiling(True)
-        com, _ = ctx.commit(evals, want_roots=False, hint_cols=cols if args.hint else None)
-        if args.serial:
-            ctx.synchronize()
-        com.open(evals, coeffs, cols, q0, zf, out=proof)
-        com.free()
+        for hinted in ((True, False) if args.both else (args.hint,)):
+            com, _ = ctx.commit(evals, want_roots=False, hint_cols=cols if hinted else None)
+            if args.serial:
+                ctx.synchronize()
+            com.open(evals, coeffs, cols, q0, zf, out=proof)
+            com.free()
         c2, _ = ctx.commit(evals, with_merkle=False)
         c2.free()
     ctx.synchronize()
     t = ctx.profile_read()
     for k, (n, ms) in sorted(t.items()):
         print(f"{k:28s} launches {n:3d}  avg {ms / n:8.4f} ms")
+    print(f"shader clock during the last commit kernel: {ctx.commit_clock_mhz():.0f} MHz")
 
 
 if __name__ == "__main__":

@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
 """Condenses rocprofv3 output directories into the tracked summaries under profiles/.
 
-  tools/pmc_summary.py --trace DIR --fetch DIR --write DIR --tag round1 --num-vars 24
+  tools/pmc_summary.py --tag round2 --num-vars 24 --trace DIR [--fetch DIR --write DIR --sq DIR] [--cal DIR]
+                       [--name-suffix _2pow26] [--verify DIR --sumcheck DIR --prover DIR]
 
-* <tag>_kernel_stats.csv : the --kernel-trace --stats table (per-kernel calls / total / average ns)
-* <tag>_pmc.md           : FETCH_SIZE / WRITE_SIZE per kernel, gfx950 read correction applied
-* pmc_traffic.json       : HBM bytes per launch of the dominant kernel, read by bench.py (`roofline.traffic`)
+* <tag><suffix>_kernel_stats.csv : the --kernel-trace --stats table (per-kernel calls / total / average ns)
+* <tag><suffix>_pmc.md           : FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU per kernel and launch
+* pmc_traffic.json               : per (kernel, num_vars, mode) HBM bytes and VALU wave-instructions per launch, read by
+                                   bench.py for `roofline.traffic` and `roofline_valu.insts` (merged, not overwritten)
+* <tag>_fetch_calibration.md     : tools/ubench_fetchcal under --pmc FETCH_SIZE: what the counter reads for the
+                                   access patterns of this library (--cal)
 """
 import argparse
 import collections
@@ -24,71 +28,105 @@ def find(d, pattern):
 
 
 def pmc(d, counter):
-    out = collections.defaultdict(list)
-    f = find(d, "*counter_collection.csv")
+    """{kernel name: [value per dispatch]}, summed over the counter's dimensions (XCDs ...) per dispatch."""
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    f = find(d, "*counter_collection.csv") if d else None
     if not f:
-        return out
+        return {}
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
-            out[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return out
+            per[r["Kernel_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    return {k: list(v.values()) for k, v in per.items()}
+
+
+def avg(x):
+    return sum(x) / len(x) if x else 0.0
+
+
+def classify(kernel):
+    """(short name, mode) of the kernels bench.py prices."""
+    k = kernel
+    if "raa_commit16_kernel<" in k or "raa_commit_kernel<" in k:
+        args = k[k.index("<") + 1:k.index(">")].replace(" ", "").split(",")
+        if "raa_commit16" in k:
+            hashed, masked = args[1] == "true", (len(args) > 2 and args[2] == "true")
+        else:
+            hashed, masked = args[1] == "true", (len(args) > 2 and args[2] == "true")
+        if not hashed:
+            return None
+        return "raa_commit_kernel", "hinted" if masked else "plain"
+    if "open_columns_kernel" in k:
+        return "open_columns_kernel", "any"
+    return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trace"), ap.add_argument("--fetch"), ap.add_argument("--write")
     ap.add_argument("--sq"), ap.add_argument("--verify"), ap.add_argument("--sumcheck"), ap.add_argument("--prover")
-    ap.add_argument("--tag", default="round1")
+    ap.add_argument("--cal")
+    ap.add_argument("--tag", default="round2")
+    ap.add_argument("--name-suffix", default="")
     ap.add_argument("--num-vars", type=int, default=24)
     a = ap.parse_args()
     prof = os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
+    tag = a.tag + a.name_suffix
     if a.trace:
         st = find(a.trace, "*kernel_stats.csv")
         if st:
-            shutil.copy(st, os.path.join(prof, f"{a.tag}_kernel_stats.csv"))
+            shutil.copy(st, os.path.join(prof, f"{tag}_kernel_stats.csv"))
     for d, name in ((a.verify, "verify"), (a.sumcheck, "sumcheck"), (a.prover, "prover")):
         st = find(d, "*kernel_stats.csv") if d else None
         if st:
             shutil.copy(st, os.path.join(prof, f"{a.tag}_{name}_kernel_stats.csv"))
-    fetch, write = pmc(a.fetch, "FETCH_SIZE") if a.fetch else {}, pmc(a.write, "WRITE_SIZE") if a.write else {}
-    lines = [f"# {a.tag}: HBM traffic per launch from rocprofv3 --pmc (separate passes)", "",
-             "FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide",
-             "streaming read (MI355X_MICROARCH.md, HBM section): the `read x2` column applies that correction; for",
-             "the 32-byte gathers of open_columns_kernel the uncorrected value already matches the distinct-line",
-             "estimate of DESIGN.md, so both are shown.", "",
-             "| kernel | launches | FETCH_SIZE KiB | WRITE_SIZE KiB | bytes (read x2 + write) | bytes (read x1 + write) |",
-             "|---|---|---|---|---|---|"]
-    traffic = {}
-    for k in sorted(set(fetch) | set(write)):
-        fk = sum(fetch.get(k, [0])) / max(len(fetch.get(k, [])), 1)
-        wk = sum(write.get(k, [0])) / max(len(write.get(k, [])), 1)
-        b2, b1 = int((2 * fk + wk) * 1024), int((fk + wk) * 1024)
-        lines.append(f"| `{k[:70]}` | {len(fetch.get(k, write.get(k, [])))} | {fk:,.0f} | {wk:,.0f} | {b2:,} | {b1:,} |")
-        short = "raa_commit_kernel" if "raa_commit_kernel<" in k and ", true>" in k else (
-            "open_columns_kernel" if "open_columns_kernel" in k else None)
-        if short:
-            traffic[short] = {"num_vars": a.num_vars, "fetch_kib": fk, "write_kib": wk,
-                              "traffic_bytes": b2 if short == "raa_commit_kernel" else b1,
-                              "source": f"profiles/{a.tag}_pmc.md"}
-    if a.sq:
-        # VALU utilisation of each kernel: issued VALU wave-instructions (one per 4 SIMD cycles) against the
-        # SIMD cycles of its launch, SQ_BUSY_CYCLES being per shader engine x 4 SIMDs ... the ratio that is
-        # unit-free is SQ_ACTIVE_INST_VALU (quad-cycles a VALU instruction was executing) / SQ_WAVE_CYCLES
-        # (quad-cycles waves were resident) x waves per SIMD; both are listed as collected.
-        sq = {c: pmc(a.sq, c) for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU")}
-        lines += ["", "## SQ counters per launch (one pass)", "",
-                  "| kernel | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU | SQ_WAVE_CYCLES | SQ_BUSY_CYCLES |", "|---|---|---|---|---|"]
-        for k in sorted(set().union(*[set(v) for v in sq.values()])):
-            avg = lambda c: sum(sq[c].get(k, [0])) / max(len(sq[c].get(k, [])), 1)
-            lines.append(f"| `{k[:70]}` | {avg('SQ_INSTS_VALU'):,.0f} | {avg('SQ_ACTIVE_INST_VALU'):,.0f} | "
-                         f"{avg('SQ_WAVE_CYCLES'):,.0f} | {avg('SQ_BUSY_CYCLES'):,.0f} |")
-    with open(os.path.join(prof, f"{a.tag}_pmc.md"), "w") as fh:
-        fh.write("\n".join(lines) + "\n")
-    if traffic:
-        with open(os.path.join(prof, "pmc_traffic.json"), "w") as fh:
-            json.dump(traffic, fh, indent=1)
-    print("\n".join(lines))
+    if a.cal:
+        fe = pmc(a.cal, "FETCH_SIZE")
+        useful = {"cal_stream16": 4 << 20, "cal_stream8": 4 << 20, "cal_gather32": None}
+        lines = [f"# {a.tag}: what FETCH_SIZE counts (tools/ubench_fetchcal under rocprofv3 --pmc FETCH_SIZE)", "",
+                 "Every byte is read exactly once from a 4 GiB buffer (16x the Infinity Cache).  `useful` = bytes the",
+                 "kernel asked for; ratio = FETCH_SIZE / useful.", "",
+                 "| kernel (dispatch) | pattern | useful KiB | FETCH_SIZE KiB | ratio |", "|---|---|---|---|---|"]
+        pats = {"cal_stream16": ["16 B per lane, streaming"], "cal_stream8": ["8 B per lane, streaming"],
+                "cal_gather32": ["2 lanes x 16 B per 32-byte node, nodes 128 B apart, random order",
+                                 "2 lanes x 16 B per 32-byte node, nodes 64 B apart, random order"]}
+        usef = {"cal_stream16": [4 << 20], "cal_stream8": [4 << 20], "cal_gather32": [1 << 20, 2 << 20]}
+        for k, vals in sorted(fe.items()):
+            short = next((s for s in pats if s in k), None)
+            if not short:
+                continue
+            for i, v in enumerate(vals):
+                u = usef[short][min(i, len(usef[short]) - 1)]
+                lines.append(f"| `{short}` ({i}) | {pats[short][min(i, len(pats[short]) - 1)]} | {u:,} | {v:,.0f} | {v / u:.3f} |")
+        with open(os.path.join(prof, f"{a.tag}_fetch_calibration.md"), "w") as fh:
+            fh.write("\n".join(lines) + "\n")
+        print("\n".join(lines))
+    fetch, write = pmc(a.fetch, "FETCH_SIZE"), pmc(a.write, "WRITE_SIZE")
+    insts = pmc(a.sq, "SQ_INSTS_VALU")
+    if fetch or write or insts:
+        lines = [f"# {tag}: per-launch counters from rocprofv3 --pmc (separate passes), num_vars = {a.num_vars}", "",
+                 "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; how to read FETCH_SIZE for each access pattern",
+                 f"is measured in `{a.tag}_fetch_calibration.md`.  SQ_INSTS_VALU = VALU wave-instructions issued.", "",
+                 "| kernel | launches | FETCH_SIZE KiB | WRITE_SIZE KiB | SQ_INSTS_VALU |", "|---|---|---|---|---|"]
+        path = os.path.join(prof, "pmc_traffic.json")
+        try:
+            traffic = json.load(open(path))
+        except (OSError, ValueError):
+            traffic = {}
+        for k in sorted(set(fetch) | set(write) | set(insts)):
+            fk, wk, ik = avg(fetch.get(k, [])), avg(write.get(k, [])), avg(insts.get(k, []))
+            n = max(len(fetch.get(k, [])), len(write.get(k, [])), len(insts.get(k, [])))
+            lines.append(f"| `{k[:80]}` | {n} | {fk:,.0f} | {wk:,.0f} | {ik:,.0f} |")
+            cl = classify(k)
+            if cl:
+                traffic[f"{cl[0]}:{a.num_vars}:{cl[1]}"] = {
+                    "kernel": k[:120], "num_vars": a.num_vars, "mode": cl[1], "fetch_kib": fk, "write_kib": wk,
+                    "valu_insts": ik, "source": f"profiles/{tag}_pmc.md"}
+        with open(os.path.join(prof, f"{tag}_pmc.md"), "w") as fh:
+            fh.write("\n".join(lines) + "\n")
+        with open(path, "w") as fh:
+            json.dump(traffic, fh, indent=1, sort_keys=True)
+        print("\n".join(lines))
 
 
 if __name__ == "__main__":

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = (
     "zip_ctx_last_error", "zip_ctx_synchronize", "zip_ctx_stream", "zip_commit", "zip_commit_hinted", "zip_commitment_free",
     "zip_commitment_device_ptrs", "zip_commit_download", "zip_commitment_upload", "zip_open_testing",
     "zip_open_columns", "zip_open_eval", "zip_proof_len", "zip_open", "zip_sum_partials", "zip_merkle_trees",
-    "zip_ctx_set_profiling", "zip_ctx_profile_read", "zip_verify", "zip_mle_eval", "zip_commitment_mle_eval", "zip_field_map_int256",
+    "zip_ctx_set_profiling", "zip_ctx_profile_read", "zip_ctx_commit_clock", "zip_verify", "zip_mle_eval", "zip_commitment_mle_eval", "zip_field_map_int256",
     "zip_open_stream", "zip_sumcheck_init", "zip_sumcheck_round", "zip_sumcheck_round_begin", "zip_sumcheck_round_end", "zip_sumcheck_last_error", "zip_sumcheck_free",
     "zip_ccs_create", "zip_ccs_free", "zip_ccs_last_error", "zip_ccs_set_z", "zip_ccs_eq_table",
     "zip_ccs_second_table", "zip_ccs_table", "zip_ccs_download", "zip_ccs_eval_matrices",
@@ -178,6 +178,8 @@ def lib():
     L.zip_merkle_trees.argtypes = [C.c_int32, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u8p]
     L.zip_ctx_set_profiling.argtypes = [vp, C.c_int32]
     L.zip_ctx_profile_read.argtypes = [vp, C.POINTER(KernelTime), C.c_uint32]
+    L.zip_ctx_commit_clock.argtypes = [vp, C.POINTER(C.c_double)]
+    L.zip_ctx_commit_clock.restype = C.c_int32
     for fn in ("zip_ctx_create", "zip_ctx_synchronize", "zip_commit", "zip_commit_hinted", "zip_commitment_device_ptrs",
                "zip_commit_download", "zip_commitment_upload", "zip_open_testing", "zip_open_columns",
                "zip_open_eval", "zip_open", "zip_sum_partials", "zip_merkle_trees", "zip_ctx_set_profiling",
@@ -389,6 +391,12 @@ class ZipContext:
         if n < 0:
             self._check(n, "zip_ctx_profile_read")
         return {buf[i].name.decode(): (buf[i].launches, buf[i].total_ms) for i in range(min(n, 32))}
+
+    def commit_clock_mhz(self):
+        """Shader clock held during the most recent profiled commit kernel (0.0 if none)."""
+        mhz = C.c_double(0.0)
+        self._check(lib().zip_ctx_commit_clock(self._h, C.byref(mhz)), "zip_ctx_commit_clock")
+        return mhz.value
 
 
 class Commitment:

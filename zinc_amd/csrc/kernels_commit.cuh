@@ -44,6 +44,10 @@ struct CommitArgs {
     // of level l is the sibling of an opened path ((i ^ 1) == c >> l for an opened column c).  Levels >= 3 are
     // always stored (the in-kernel upper levels read level 3 back, and above it nearly every node is needed).
     const uint32_t *need;
+    // measurement hook (zip_ctx_set_profiling): workgroup 0 stamps {s_memtime, s_memrealtime} at its start and at
+    // its end into clock[0..3] -- the shader clock the chip actually held during THIS launch (the VALU roofline
+    // of bench.py is priced at that clock, not at a datasheet figure)
+    unsigned long long *clock;
 #ifdef ZIPK_DEBUG_STAMPS
     unsigned long long *stamps;  // tools/ubench_pipeline.hip: [chunk][workgroup] wall-clock of each arrival
 #endif
@@ -315,6 +319,13 @@ __device__ __forceinline__ void finish_chunk(const CommitArgs &a, uint32_t first
     }
 }
 
+__device__ __forceinline__ void stamp_clock(const CommitArgs &a, int slot) {
+    if (a.clock && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.clock[2 * slot] = __builtin_amdgcn_s_memtime();
+        a.clock[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
 // Returns 0 in a way the optimiser cannot see through.  Adding it to the per-row index
 // arithmetic keeps loop-invariant code motion from hoisting ~50 registers of permutation
 // indices / addresses out of the persistent row loop (which pushed the kernel to 128 VGPRs,
@@ -361,6 +372,7 @@ __global__ void __launch_bounds__(1024, MASKED ? 4 : 5) raa_commit_kernel(Commit
     const uint32_t PS = T + PAD;  // plane stride (slots)
     const uint32_t cw = a.cw, row_len = a.row_len;
     const bool active = tid0 < a.nact;
+    stamp_clock(a, 0);
 
     i128 *wave_tot = reinterpret_cast<i128 *>(smem);                  // 2 x 16 entries
     uint64_t *t2lo = reinterpret_cast<uint64_t *>(smem + 512);         // E planes of PS slots
@@ -512,6 +524,7 @@ __global__ void __launch_bounds__(1024, MASKED ? 4 : 5) raa_commit_kernel(Commit
         }
         ZIPK_PH(ph_c);
     }
+    stamp_clock(a, 1);
 #ifdef ZIPK_DEBUG_STAMPS
     if (tid0 == 0 && a.stamps) {
         unsigned long long *o = a.stamps + 64 * gridDim.x + 4 * blockIdx.x;
@@ -541,8 +554,12 @@ __global__ void __launch_bounds__(1024, MASKED ? 4 : 5) raa_commit_kernel(Commit
 // same thread: no barrier) instead of in 48 registers -- the previous variant (two 8192-entry strips
 // through LDS, three more barriers per row) spilled 59 VGPRs to scratch.
 // ---------------------------------------------------------------------------------------
-constexpr uint32_t kC16_T = 1024, kC16_PS = kC16_T + 2;  // plane stride of the 16 t2 planes
-constexpr size_t kC16_LDS = 512 + (size_t)16 * kC16_PS * 8 + (size_t)16 * kC16_PS + (size_t)kC16_T * 4;
+// T threads x 16 entries: T = 1024 for cw = 16384 (one workgroup per CU), T = 512 for cw = 8192, where TWO
+// workgroups fit a CU (2 x 74.8 KB of LDS): while one of them is in its scan passes or in the latency-bound top
+// of its tree, the other one hashes.
+constexpr size_t c16_lds_bytes(uint32_t T) {  // wave totals | t2lo [16][T+2] | t2dh [16][T+2] | ghi [T]
+    return 512 + (size_t)16 * (T + 2) * 8 + (size_t)16 * (T + 2) + (size_t)T * 4;
+}
 
 // One stage of the 8x8 transpose over the lanes of an 8-lane group: registers r and r | 2^B are
 // exchanged with lane ^ 2^B (lane bit B clear keeps x[r], set keeps x[r | 2^B]).  After B = 0, 1, 2
@@ -567,13 +584,14 @@ __device__ __forceinline__ void transpose8(uint32_t (&x)[8], uint32_t lane) {
     transpose8_stage<2>(x, (lane >> 2) & 1u);
 }
 
-template <bool HASH, bool MASKED = false>
-__global__ void __launch_bounds__(1024, 4) raa_commit16_kernel(CommitArgs a) {
+template <uint32_t T, bool HASH, bool MASKED = false>
+__global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int E = 16;
-    constexpr uint32_t T = kC16_T, PS = kC16_PS;
+    constexpr uint32_t PS = T + 2;  // plane stride of the 16 t2 planes
     const uint32_t tid0 = threadIdx.x;
-    const uint32_t cw = a.cw, row_len = a.row_len;  // 16384, 8192
+    const uint32_t cw = a.cw, row_len = a.row_len;  // 16 T, 8 T
+    stamp_clock(a, 0);
 
     i128 *wave_tot = reinterpret_cast<i128 *>(smem);
     uint64_t *t2lo = reinterpret_cast<uint64_t *>(smem + 512);           // [16][PS]
@@ -707,6 +725,7 @@ __global__ void __launch_bounds__(1024, 4) raa_commit16_kernel(CommitArgs a) {
             cc.advance(round);
         }
     }
+    stamp_clock(a, 1);
 }
 
 // [n][2] compact row entries (w0, w1, w2, sign as four 32-bit words) -> [n][4] Int<4> limbs

@@ -61,6 +61,7 @@ struct zip_ctx {
     uint32_t n_chunks = 1;
     uint32_t num_cus = 256;
     uint32_t *timeout_flag_h = nullptr, *timeout_flag_d = nullptr;  // pinned: a pipeline wait gave up
+    unsigned long long *clock_h = nullptr, *clock_d = nullptr;      // pinned: CommitArgs.clock stamps of the last profiled commit
     std::vector<hipEvent_t> dep_event_pool;  // hipEventDisableTiming
     uint32_t *perm1_d = nullptr, *perm2_d = nullptr;
     // pinned host staging for the small per-call inputs (coeffs, q0, column indices): one
@@ -660,15 +661,20 @@ int32_t launch_commit(zip_ctx *ctx, const CommitArgs &a, uint32_t threads, uint3
     return ZIP_OK;
 }
 
-// cw = 16384: raa_commit16_kernel (t2 compacted into LDS, 1024 threads x 16 entries)
-template <bool HASH, bool MASKED = false>
-int32_t launch_commit16(zip_ctx *ctx, const CommitArgs &a, uint32_t grid, hipStream_t st) {
-    auto kern = raa_commit16_kernel<HASH, MASKED>;
-    if (int32_t rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), kC16_LDS)) return rc;
+// raa_commit16_kernel (t2 compacted into LDS, T threads x 16 entries): cw = 16384 with T = 1024, cw = 8192 with T = 512
+template <uint32_t T, bool HASH, bool MASKED = false>
+int32_t launch_commit16_t(zip_ctx *ctx, const CommitArgs &a, uint32_t grid, hipStream_t st) {
+    auto kern = raa_commit16_kernel<T, HASH, MASKED>;
+    if (int32_t rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), c16_lds_bytes(T))) return rc;
     LaunchTimer t(ctx, HASH ? "raa_commit_kernel" : "raa_encode_kernel", st);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), kC16_LDS, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T), c16_lds_bytes(T), st, a);
     HIP_TRY(ctx, hipGetLastError());
     return ZIP_OK;
+}
+template <bool HASH, bool MASKED = false>
+int32_t launch_commit16(zip_ctx *ctx, const CommitArgs &a, uint32_t grid, hipStream_t st) {
+    return a.cw == 16384 ? launch_commit16_t<1024, HASH, MASKED>(ctx, a, grid, st)
+                         : launch_commit16_t<512, HASH, MASKED>(ctx, a, grid, st);
 }
 
 struct CommitGeom {
@@ -677,7 +683,12 @@ struct CommitGeom {
 };
 CommitGeom commit_geom(uint32_t cw, uint32_t row_len) {
     CommitGeom g{};
-    if (cw == 16384) { g.e = 16; g.threads = 1024; g.lds = kC16_LDS; return g; }
+    if (cw == 16384) { g.e = 16; g.threads = 1024; g.lds = c16_lds_bytes(1024); return g; }
+    // cw = 8192, opt-in (ZIP_HIP_WIDE=1): two 512-thread workgroups of the 16-entry kernel per CU instead of one
+    // 1024-thread workgroup of the 8-entry kernel.  Measured: 1.57 ms against 1.53 ms alone at 2^24 -- both sit
+    // at the same share of the VALU issue rate, a second workgroup hides nothing -- and it leaves the gather 10 KB of LDS.
+    static const bool wide = getenv("ZIP_HIP_WIDE") && atoi(getenv("ZIP_HIP_WIDE")) == 1;
+    if (cw == 8192 && row_len == 4096 && wide) { g.e = 16; g.threads = 512; g.lds = c16_lds_bytes(512); return g; }
     if (cw >= 512) { g.e = 8; g.threads = cw / 8; }
     else if (cw == 256) { g.e = 4; g.threads = 64; }
     else if (cw == 128) { g.e = 2; g.threads = 64; }
@@ -912,7 +923,21 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
     a.k_limbs = ctx->p.k_limbs;
     a.row_lo = row_lo;
     a.row_hi = row_hi;
-    a.rows_per_block = (row_hi - row_lo) < 32 ? (row_hi - row_lo) : 32;  // the value copy needs <= 128
+    // Rows per workgroup: 32, or fewer where the LDS image of 32 path records would not fit beside the persistent
+    // commit workgroups of this geometry -- the gather is meant to run BESIDE them (at cw = 16384 the commit kernel
+    // leaves 11.5 KB per CU and 32 records are 14.6 KB: the gathers then only started when the commit ended).
+    static const uint32_t knob_rpb = getenv("ZIP_HIP_GATHER_RPB") ? (uint32_t)atoi(getenv("ZIP_HIP_GATHER_RPB")) : 0u;
+    uint32_t rpb = 32u;
+    if (knob_rpb >= 2 && knob_rpb <= 128) {
+        rpb = knob_rpb & ~1u;  // even; the value copy needs <= 128
+    } else {
+        const CommitGeom cg = commit_geom(ctx->p.codeword_len, ctx->p.row_len);
+        const size_t used = (size_t)commit_wgs_per_cu(cg) * cg.lds, rec = 8 + 32 * (size_t)ctx->depth;
+        const size_t free_lds = used < 160u * 1024u ? 160u * 1024u - used : 0;
+        // (2.5 KB of slack: LDS is handed out in granules -- 24 records = 10.7 KB did NOT get in beside 148.8 KB)
+        while (rpb > 8 && rpb * rec + 2560 > free_lds) rpb -= 8;
+    }
+    a.rows_per_block = (row_hi - row_lo) < rpb ? (row_hi - row_lo) : rpb;
     static const int knob_prio = getenv("ZIP_HIP_GATHER_PRIO") ? atoi(getenv("ZIP_HIP_GATHER_PRIO")) : 1;
     a.prio = (uint32_t)knob_prio;
     const size_t lds = (size_t)a.rows_per_block * (8 + 32 * (size_t)ctx->depth);
@@ -1447,6 +1472,12 @@ int32_t zip_ctx_create(const zip_params *p, zip_ctx **out) {
             break;
         }
         *ctx->timeout_flag_h = 0;
+        ctx->clock_h = reinterpret_cast<unsigned long long *>(ctx->pinned_base + 256);
+        memset(ctx->clock_h, 0, 32);
+        if (hipHostGetDevicePointer((void **)&ctx->clock_d, ctx->clock_h, 0) != hipSuccess) {
+            rc = ZIP_ERR_ALLOC;
+            break;
+        }
         // pipeline chunks: the persistent commit kernel publishes its rows in this many groups
         // (0 = chosen per commit from the number of rounds; ZIP_HIP_CHUNKS overrides)
         ctx->n_chunks = 0;
@@ -1636,6 +1667,7 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
         a.rounds_per_chunk = rpc;
         a.chunk_ends = chunk_ends;
         a.roots = c->roots;
+        a.clock = ctx->profiling ? ctx->clock_d : nullptr;
         hipError_t e = hipSuccess;
         if (with_merkle && hint_cols && commit_supports_hint(cw)) {
             // the hint bitmaps (CommitArgs.need): V | N0 | N1 | N2, see kernels_commit.cuh
@@ -1728,6 +1760,7 @@ static int32_t rematerialize(zip_commitment *c) {
     zip_ctx *ctx = c->ctx;
     CommitArgs a = c->args;
     a.need = nullptr;
+    a.clock = nullptr;
     a.chunk_done = nullptr;  // the chunks of the first run stay published
     a.evals = c->evals ? c->evals : c->evals_ref;
     if (c->done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_commit, c->done, 0));
@@ -2833,6 +2866,16 @@ int32_t zip_merkle_trees(int32_t device, const uint64_t *leaves, uint32_t leaf_l
 int32_t zip_ctx_set_profiling(zip_ctx *ctx, int32_t on) {
     if (!ctx) return ZIP_ERR_NULL;
     ctx->profiling = on != 0;
+    return ZIP_OK;
+}
+
+int32_t zip_ctx_commit_clock(zip_ctx *ctx, double *mhz_out) {
+    if (!ctx || !mhz_out) return ZIP_ERR_NULL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
+    if (ctx->s_commit) HIP_TRY(ctx, hipStreamSynchronize(ctx->s_commit));
+    const unsigned long long *c = ctx->clock_h;
+    *mhz_out = (c && c[3] > c[1] && c[2] > c[0]) ? (double)(c[2] - c[0]) / (double)(c[3] - c[1]) * 100.0 : 0.0;
     return ZIP_OK;
 }
 
