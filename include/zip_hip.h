@@ -160,7 +160,18 @@ int32_t zip_open_testing(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_
 int32_t zip_open_columns(zip_commitment *c, const uint32_t *cols, uint32_t n_cols, uint8_t *wire_out,
                          zip_mem_kind out_kind);
 /* prove_evaluation_phase (open_z.rs:62-91): row_out row_len * field->limbs u64 (Montgomery limbs).
- * When num_rows == 1 q0_mont is ignored and row_out = map_to_field(evals). */
+ * When num_rows == 1 q0_mont is ignored and row_out = map_to_field(evals).
+ *
+ * PARITY UNPINNED -- the signed-modulus quirk.  For a modulus q whose top bit is set in its limb width with
+ * 2^(64 limbs) - q < 2^64 (e.g. q = 2^256 - 189, benches/spartan_benches.rs:134-137) the kernels first reduce |w|
+ * modulo 2^(64 limbs) - q (`quirk_mod`), because the builder READS src/field.rs:550-557 as doing so: `F::I = Int<N>`
+ * makes the modulus a NEGATIVE Int inside map_to_field's `%=`.  That reading of crypto-bigint 0.6's `Int::rem`
+ * sign semantics has no published vector and could not be run here (no cargo); it changes results only for such
+ * moduli (never for the 256-bit modulus of benches/zip_benches.rs:253: its top bit is set too, but 2^256 - q there
+ * is far above 2^64, so a 64-bit |w| is never touched), it is applied
+ * identically in zip_open_eval, zip_open, zip_verify, zip_mle_eval and zip_field_map_int256, and
+ * integration/rust/fixture_dump.rs + tests/test_rust_fixtures.py pin it the first time a maintainer runs
+ * `cargo test fixture_dump`. */
 int32_t zip_open_eval(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_kind, const uint64_t *q0_mont,
                       const zip_field *field, uint64_t *row_out, zip_mem_kind out_kind);
 /* proof length in bytes for n_cols openings (commit.rs:712-737) */

@@ -596,8 +596,18 @@ int orc_build_eq_x_r(const orc_field *f, const uint64_t *r, uint32_t nvars, uint
 
 /* ======================================================================== */
 /* rand 0.9.2 `StdRng::seed_from_u64` + `SliceRandom::shuffle`               */
-/* PARITY UNPINNED restatement of the published algorithm                    */
-/* (zip/utils.rs:139-142 is the only call site).                             */
+/* Restatement of the published algorithm of the un-vendored crates          */
+/* (zip/utils.rs:139-142 is the only call site).  Pinned piece by piece by   */
+/* published vectors (tests/golden/rand_vectors.json, tests/test_oracle_kats.py): */
+/*   ChaCha12 block           draft-strombergson-chacha-test-vectors TC1     */
+/*   StdRng = ChaCha12, word / counter layout, next_u64                      */
+/*                            rand's own test_stdrng_construction            */
+/*   PCG32 step + XSH-RR      O'Neill's pcg32 demo (seed 42, stream 54)      */
+/*   IncreasingUniform shuffle + Canon's-method random_range                 */
+/*                            rand's value_stability_slice (Pcg32(414))      */
+/* NOT pinned by any vector: the eight lines of rand_core's seed_from_u64    */
+/* that chain these (advance-then-output PCG32 with the fixed increment,     */
+/* 4 bytes little-endian per step).                                          */
 /* ======================================================================== */
 typedef struct {
     uint32_t key[8];
@@ -635,29 +645,52 @@ static void chacha12_block(chacha12_rng *g) {
     g->idx = 0;
 }
 
+/* PCG XSH-RR 64/32 output function and LCG step (O'Neill); rand_core and rand_pcg both build on them */
+static inline uint32_t pcg32_output(uint64_t state) {
+    uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+    uint32_t rot = (uint32_t)(state >> 59);
+    return (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+}
+static inline uint64_t pcg32_step(uint64_t state, uint64_t inc) { return state * 6364136223846793005ULL + inc; }
+
 static void chacha12_seed_from_u64(chacha12_rng *g, uint64_t state) {
-    /* rand_core SeedableRng::seed_from_u64: PCG32 stream fills the 32-byte seed */
+    /* rand_core SeedableRng::seed_from_u64: the state is advanced FIRST, then the PCG output function of the new
+     * state gives 4 seed bytes (little-endian), eight times */
     for (int i = 0; i < 8; i++) {
-        state = state * 6364136223846793005ULL + 11634580027462260723ULL;
-        uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
-        uint32_t rot = (uint32_t)(state >> 59);
-        g->key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+        state = pcg32_step(state, 11634580027462260723ULL);
+        g->key[i] = pcg32_output(state);
     }
     g->counter = 0;
     g->idx = 16;
 }
 
-static uint32_t chacha12_next_u32(chacha12_rng *g) {
+static uint32_t chacha12_next_u32(void *p) {
+    chacha12_rng *g = (chacha12_rng *)p;
     if (g->idx >= 16) chacha12_block(g);
     return g->buf[g->idx++];
 }
 
+/* rand_pcg::Lcg64Xsh32 (= Pcg32), the generator rand's own value-stability tests run on */
+typedef struct { uint64_t state, inc; } pcg32_rng;
+static void pcg32_new(pcg32_rng *g, uint64_t state, uint64_t stream) {
+    g->inc = (stream << 1) | 1;
+    g->state = pcg32_step(state + g->inc, g->inc);
+}
+static uint32_t pcg32_next_u32(void *p) {
+    pcg32_rng *g = (pcg32_rng *)p;
+    const uint64_t old = g->state;
+    g->state = pcg32_step(old, g->inc);
+    return pcg32_output(old);
+}
+
+typedef uint32_t (*u32_source)(void *);
+
 /* UniformInt<u32>::sample_single_inclusive(0, bound-1): Canon's method, one retry */
-static uint32_t rand_range_u32(chacha12_rng *g, uint32_t bound) {
-    uint64_t m = (uint64_t)chacha12_next_u32(g) * bound;
+static uint32_t rand_range_u32(u32_source next, void *g, uint32_t bound) {
+    uint64_t m = (uint64_t)next(g) * bound;
     uint32_t result = (uint32_t)(m >> 32), lo_order = (uint32_t)m;
     if (lo_order > (uint32_t)(0u - bound)) {
-        uint64_t m2 = (uint64_t)chacha12_next_u32(g) * bound;
+        uint64_t m2 = (uint64_t)next(g) * bound;
         uint32_t new_hi = (uint32_t)(m2 >> 32);
         uint32_t sum = lo_order + new_hi;
         result += (sum < lo_order); /* checked_add(..).is_none() */
@@ -665,9 +698,8 @@ static uint32_t rand_range_u32(chacha12_rng *g, uint32_t bound) {
     return result;
 }
 
-void orc_shuffle_seeded_perm(uint64_t seed, uint32_t len, uint32_t *perm) {
-    chacha12_rng g;
-    chacha12_seed_from_u64(&g, seed);
+/* SliceRandom::shuffle of [0, len) (rand 0.9 seq/slice.rs + seq/increasing_uniform.rs) over any u32 source */
+static void shuffle_perm(u32_source next, void *g, uint32_t len, uint32_t *perm) {
     for (uint32_t i = 0; i < len; i++) perm[i] = i;
     if (len <= 1) return;
     /* IncreasingUniform::new(rng, 0) */
@@ -688,7 +720,7 @@ void orc_shuffle_seeded_perm(uint64_t seed, uint32_t len, uint32_t *perm) {
                 current++;
             }
             uint8_t remaining = (uint8_t)(current - next_n);
-            chunk = rand_range_u32(&g, product);
+            chunk = rand_range_u32(next, g, product);
             next_rem = (uint8_t)(remaining - 1);
         }
         if (next_rem == 0) {
@@ -703,6 +735,51 @@ void orc_shuffle_seeded_perm(uint64_t seed, uint32_t len, uint32_t *perm) {
         perm[i] = perm[result];
         perm[result] = t;
     }
+}
+
+void orc_shuffle_seeded_perm(uint64_t seed, uint32_t len, uint32_t *perm) {
+    chacha12_rng g;
+    chacha12_seed_from_u64(&g, seed);
+    shuffle_perm(chacha12_next_u32, &g, len, perm);
+}
+
+/* ---- known-answer hooks for the pieces above (tests/test_oracle_kats.py) ---- */
+void orc_kat_chacha12_block(const uint32_t key[8], uint64_t counter, uint32_t out[16]) {
+    chacha12_rng g;
+    memcpy(g.key, key, sizeof g.key);
+    g.counter = counter;
+    chacha12_block(&g);
+    memcpy(out, g.buf, sizeof g.buf);
+}
+/* StdRng::from_seed(seed).next_u64() ... : n consecutive u64 (two u32 words each, low word first) */
+void orc_kat_stdrng_from_seed_u64(const uint8_t seed[32], uint32_t n, uint64_t *out) {
+    chacha12_rng g;
+    for (int i = 0; i < 8; i++)
+        g.key[i] = (uint32_t)seed[4 * i] | ((uint32_t)seed[4 * i + 1] << 8) | ((uint32_t)seed[4 * i + 2] << 16) |
+                   ((uint32_t)seed[4 * i + 3] << 24);
+    g.counter = 0;
+    g.idx = 16;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t lo = chacha12_next_u32(&g), hi = chacha12_next_u32(&g);
+        out[i] = lo | (hi << 32);
+    }
+}
+void orc_kat_pcg32(uint64_t state, uint64_t stream, uint32_t n, uint32_t *out) {
+    pcg32_rng g;
+    pcg32_new(&g, state, stream);
+    for (uint32_t i = 0; i < n; i++) out[i] = pcg32_next_u32(&g);
+}
+/* [0, len).shuffle(&mut Pcg32::new(state, stream)) */
+void orc_kat_shuffle_pcg32(uint64_t state, uint64_t stream, uint32_t len, uint32_t *perm) {
+    pcg32_rng g;
+    pcg32_new(&g, state, stream);
+    shuffle_perm(pcg32_next_u32, &g, len, perm);
+}
+/* the 32-byte seed seed_from_u64 expands `state` to (the unpinned link) */
+void orc_kat_seed_from_u64(uint64_t state, uint32_t key_out[8]) {
+    chacha12_rng g;
+    chacha12_seed_from_u64(&g, state);
+    memcpy(key_out, g.key, sizeof g.key);
 }
 
 /* ======================================================================== */

@@ -20,10 +20,15 @@
  *    src/zip/code_raa.rs:199-244, src/zip/pcs/utils.rs:301-337,
  *    src/zip/utils.rs:164-234.
  *  - rand 0.9 `StdRng::seed_from_u64` + `SliceRandom::shuffle`
- *    (orc_shuffle_seeded_perm): restated from the published algorithm; the
- *    reference pins no permutation, the crates are not vendored and there is
- *    no Rust toolchain here, so THIS PIECE IS "parity unpinned".  The product
- *    ABI takes explicit permutation tables so nothing on the GPU depends on it.
+ *    (orc_shuffle_seeded_perm): restated from the published algorithm of the
+ *    un-vendored crates; the reference pins no permutation.  Pinned piece by
+ *    piece by published vectors (tests/golden/rand_vectors.json): the ChaCha12
+ *    block, StdRng's word/counter layout (rand's test_stdrng_construction),
+ *    PCG32 (O'Neill's demo), the IncreasingUniform shuffle with Canon's-method
+ *    random_range (rand's value_stability_slice).  The one link WITHOUT a
+ *    vector is rand_core's seed_from_u64 (PCG32 expansion of the u64 seed):
+ *    that link stays "parity unpinned".  The product ABI takes explicit
+ *    permutation tables, so nothing on the GPU depends on any of this.
  *  - The reference itself (Rust) cannot be built in this image (no cargo/rustc,
  *    no vendored crates), so there is no oracle/_ref.
  *
@@ -100,9 +105,15 @@ void orc_tr_absorb_field(orc_keccak *k, const orc_field *f, const uint64_t *val)
 int orc_build_eq_x_r(const orc_field *f, const uint64_t *r, uint32_t nvars, uint64_t *out);
 
 /* ---------------------------------------------------------------- shuffle */
-/* rand 0.9 restatement (PARITY UNPINNED).  Fills perm with the permutation such
+/* rand 0.9 restatement (see the header comment for what is pinned).  Fills perm with the permutation such
  * that shuffle_seeded(x, seed)[j] == x[perm[j]]  (zip/utils.rs:139-142). */
 void orc_shuffle_seeded_perm(uint64_t seed, uint32_t len, uint32_t *perm);
+/* known-answer hooks for its pieces (tests/test_oracle_kats.py, tests/golden/rand_vectors.json) */
+void orc_kat_chacha12_block(const uint32_t key[8], uint64_t counter, uint32_t out[16]);
+void orc_kat_stdrng_from_seed_u64(const uint8_t seed[32], uint32_t n, uint64_t *out);
+void orc_kat_pcg32(uint64_t state, uint64_t stream, uint32_t n, uint32_t *out);
+void orc_kat_shuffle_pcg32(uint64_t state, uint64_t stream, uint32_t len, uint32_t *perm);
+void orc_kat_seed_from_u64(uint64_t state, uint32_t key_out[8]);
 
 /* ---------------------------------------------------------------- RAA code */
 /* RaaCode::encode_inner (code_raa.rs:89-105) on one row, explicit permutations.

@@ -340,6 +340,38 @@ def build_eq_x_r(f: Field, r: np.ndarray) -> np.ndarray:
     return out
 
 
+def kat_chacha12_block(key_words, counter) -> bytes:
+    key = (C.c_uint32 * 8)(*key_words)
+    out = (C.c_uint32 * 16)()
+    lib().orc_kat_chacha12_block(key, C.c_uint64(counter), out)
+    return b"".join(int(w).to_bytes(4, "little") for w in out)
+
+
+def kat_stdrng_u64(seed_bytes, n):
+    seed = (C.c_uint8 * 32)(*seed_bytes)
+    out = (C.c_uint64 * n)()
+    lib().orc_kat_stdrng_from_seed_u64(seed, n, out)
+    return [int(x) for x in out]
+
+
+def kat_pcg32(state, stream, n):
+    out = (C.c_uint32 * n)()
+    lib().orc_kat_pcg32(C.c_uint64(state), C.c_uint64(stream), n, out)
+    return [int(x) for x in out]
+
+
+def kat_shuffle_pcg32(state, stream, length):
+    perm = np.zeros(length, dtype=np.uint32)
+    lib().orc_kat_shuffle_pcg32(C.c_uint64(state), C.c_uint64(stream), length, _u32p(perm))
+    return perm
+
+
+def kat_seed_from_u64(state):
+    out = (C.c_uint32 * 8)()
+    lib().orc_kat_seed_from_u64(C.c_uint64(state), out)
+    return [int(x) for x in out]
+
+
 def shuffle_perm(seed: int, length: int) -> np.ndarray:
     perm = np.zeros(length, dtype=np.uint32)
     lib().orc_shuffle_seeded_perm(C.c_uint64(seed), length, _u32p(perm))

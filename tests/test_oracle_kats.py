@@ -278,13 +278,62 @@ def test_merkle_layout_and_all_proofs():
     assert orc.merkle_verify(depth, orc.merkle_path(depth, layers, 5), root, bad, 5) != 0
 
 
-# ------------------------------------------------------------- shuffle (unpinned)
+# ------------------------------------------------------------- shuffle: pinned piece by piece
+def _rand_vectors():
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "rand_vectors.json")) as fh:
+        return json.load(fh)
+
+
 def test_shuffle_is_permutation_deterministic_and_seed_dependent():
-    """src/zip/code_raa.rs:246-276.  NOTE: orc_shuffle_seeded_perm restates rand 0.9
-    from its published algorithm; no reference test pins its output (parity unpinned)."""
+    """src/zip/code_raa.rs:246-276 (the reference's own tests of shuffle_seeded pin no permutation)."""
     a = orc.shuffle_perm(12345, 512)
     assert sorted(a) == list(range(512))
     assert np.array_equal(a, orc.shuffle_perm(12345, 512))
     assert not np.array_equal(a, orc.shuffle_perm(54321, 512))
     assert not np.array_equal(a, np.arange(512))
     assert list(orc.shuffle_perm(1, 1)) == [0]
+
+
+def test_chacha12_block_matches_the_published_vector():
+    v = _rand_vectors()["chacha12_zero_key_block0"]
+    assert orc.kat_chacha12_block(v["key_words"], v["counter"]).hex() == v["keystream_hex"]
+
+
+def test_stdrng_is_chacha12_with_rands_own_construction_vector():
+    v = _rand_vectors()["stdrng_construction"]
+    assert orc.kat_stdrng_u64(v["seed_bytes"], 1) == [int(v["next_u64"])]
+
+
+def test_pcg32_matches_oneills_demo_outputs():
+    v = _rand_vectors()["pcg32_demo"]
+    assert [f"{x:08x}" for x in orc.kat_pcg32(v["state"], v["stream"], 6)] == v["outputs_hex"]
+
+
+def test_shuffle_algorithm_matches_rands_value_stability_vector():
+    """IncreasingUniform + Canon's-method random_range + the swap order of SliceRandom::shuffle, driven by the
+    generator rand's own test uses (Pcg32): the expected permutation is rand 0.9's value_stability_slice."""
+    v = _rand_vectors()["shuffle_value_stability"]
+    got = orc.kat_shuffle_pcg32(v["pcg32_state"], int(v["pcg32_stream"]), v["len"])
+    # shuffle of [0..13): shuffled[j] = x[perm[j]] with x the identity
+    assert list(got) == v["shuffled"]
+
+
+def test_seed_from_u64_link_is_the_documented_pcg32_expansion():
+    """The one link without a published vector: what is checked here is only that the oracle's seed expansion IS
+    the procedure its header describes (PCG32 steps with rand_core's increment, output of the NEW state), written a
+    second time in Python; `orc_shuffle_seeded_perm` = that seed -> ChaCha12 -> the pinned shuffle."""
+    M = (1 << 64) - 1
+    for seed in (0, 1, 2, 0xDEADBEEF, M):
+        state, want = seed, []
+        for _ in range(8):
+            state = (state * 6364136223846793005 + 11634580027462260723) & M
+            xs = (((state >> 18) ^ state) >> 27) & 0xFFFFFFFF
+            rot = state >> 59
+            want.append(((xs >> rot) | (xs << ((32 - rot) & 31))) & 0xFFFFFFFF)
+        assert orc.kat_seed_from_u64(seed) == want
+        # and the ChaCha12 stream under that key starts the shuffle: first block reproduced through the block KAT
+        blk = orc.kat_chacha12_block(want, 0)
+        assert orc.kat_stdrng_u64(b"".join(w.to_bytes(4, "little") for w in want), 1)[0] == int.from_bytes(blk[:8], "little")

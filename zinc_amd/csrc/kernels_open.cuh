@@ -366,6 +366,8 @@ struct OpenColsArgs {
     uint32_t row_lo, row_hi;  // rows handled by this launch (one pipeline chunk)
     uint32_t rows_per_block;  // even, or the launch has a single block row
     uint32_t prio;            // s_setprio level of the gather waves (tuning knob)
+    uint32_t exp_skip_low;    // TIMING EXPERIMENT ONLY (ZIP_HIP_EXP_SKIP_LOW): neither read nor move the values and the
+                              // siblings below this level -- the proof is then wrong
 };
 
 // Grid (n_cols, row blocks): blocks that run together share a narrow band of rows, so the
@@ -408,7 +410,7 @@ __global__ void __launch_bounds__(256) open_columns_kernel(OpenColsArgs a) {
         unsigned char *dst = img + (size_t)rsub * rec_bytes + 8 + (size_t)h * 16;
         const size_t src_step = (size_t)RPP * cw2 * 4;
         const uint32_t dst_step = RPP * rec_bytes;
-        if (h < 2 * d) {
+        if (h < 2 * d && lvl >= a.exp_skip_low) {
 #pragma unroll 4
             for (uint32_t rr = rsub; rr < nrows; rr += RPP, src += src_step, dst += dst_step) {
                 const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src);
@@ -424,7 +426,7 @@ __global__ void __launch_bounds__(256) open_columns_kernel(OpenColsArgs a) {
     // ---- column values: rows[r*cw + col], K limbs little-endian (open_z.rs:130-137) ----
     {
         const uint32_t half = threadIdx.x & 1, rsub = threadIdx.x >> 1;  // two 16-byte halves per value
-        if (rsub < nrows) {
+        if (rsub < nrows && !a.exp_skip_low) {
             const uint32_t r = r0 + rsub;
             ulonglong2 v;
             if (a.compact_rows) {  // (w0, w1, w2, sign): the upper half of the Int<4> is the sign word four times

@@ -940,6 +940,8 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
     a.rows_per_block = (row_hi - row_lo) < rpb ? (row_hi - row_lo) : rpb;
     static const int knob_prio = getenv("ZIP_HIP_GATHER_PRIO") ? atoi(getenv("ZIP_HIP_GATHER_PRIO")) : 1;
     a.prio = (uint32_t)knob_prio;
+    static const uint32_t knob_skip = getenv("ZIP_HIP_EXP_SKIP_LOW") ? (uint32_t)atoi(getenv("ZIP_HIP_EXP_SKIP_LOW")) : 0u;
+    a.exp_skip_low = knob_skip;
     const size_t lds = (size_t)a.rows_per_block * (8 + 32 * (size_t)ctx->depth);
     const dim3 grid(n_cols, (row_hi - row_lo + a.rows_per_block - 1) / a.rows_per_block), block(256);
     LaunchTimer t(ctx, "open_columns_kernel");

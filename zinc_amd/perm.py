@@ -4,12 +4,14 @@ Mirrors `shuffle_seeded` (src/zip/utils.rs:139-142): `StdRng::seed_from_u64(seed
 then `SliceRandom::shuffle`, applied to the identity so that
 `shuffle_seeded(x, seed)[j] == x[perm[j]]`.
 
-PARITY UNPINNED: rand 0.9.2 / rand_chacha are not vendored in the reference and no
-reference test pins a permutation, so this restates the crates' published
-algorithm (PCG32 seed expansion -> ChaCha12 block RNG -> IncreasingUniform
-Fisher-Yates with Canon's-method `random_range`).  In the Rust integration the shim
-calls the real `shuffle_seeded` on `[0..codeword_len)` and passes the table through
-the FFI, so nothing on the GPU side depends on this file.
+rand 0.9.2 / rand_chacha are not vendored in the reference and no reference test pins a
+permutation, so this restates the crates' published algorithm (PCG32 seed expansion ->
+ChaCha12 block RNG -> IncreasingUniform Fisher-Yates with Canon's-method `random_range`).
+Every piece except the seed expansion is pinned by a published vector
+(tests/golden/rand_vectors.json, tests/test_host_mirror.py); `seed_from_u64` itself is the
+one link that stays parity-unpinned.  In the Rust integration the shim calls the real
+`shuffle_seeded` on `[0..codeword_len)` and passes the table through the FFI, so nothing
+on the GPU side depends on this file.
 """
 import numpy as np
 
@@ -21,17 +23,49 @@ def _rotl(x, n):
     return ((x << n) | (x >> (32 - n))) & _M32
 
 
-class ChaCha12Rng:
+def _pcg32_output(state):
+    """PCG XSH-RR 64/32 (O'Neill)."""
+    xorshifted = (((state >> 18) ^ state) >> 27) & _M32
+    rot = state >> 59
+    return ((xorshifted >> rot) | (xorshifted << ((32 - rot) & 31))) & _M32
+
+
+class _RangeMixin:
+    def random_range_u32(self, bound):
+        """UniformInt<u32>::sample_single_inclusive(0, bound - 1): Canon's method, one retry."""
+        m = self.next_u32() * bound
+        result, lo = m >> 32, m & _M32
+        if lo > ((-bound) & _M32):
+            new_hi = (self.next_u32() * bound) >> 32
+            result += 1 if lo + new_hi > _M32 else 0
+        return result
+
+
+class Pcg32(_RangeMixin):
+    """rand_pcg::Lcg64Xsh32::new(state, stream): the generator rand's own value-stability tests use."""
+
+    def __init__(self, state, stream):
+        self.inc = ((stream << 1) | 1) & _M64
+        self.state = ((state + self.inc) * 6364136223846793005 + self.inc) & _M64
+
+    def next_u32(self):
+        old = self.state
+        self.state = (old * 6364136223846793005 + self.inc) & _M64
+        return _pcg32_output(old)
+
+
+class ChaCha12Rng(_RangeMixin):
     """rand_chacha::ChaCha12Rng: 64-bit block counter, stream 0, words consumed in order."""
 
-    def __init__(self, seed_u64):
-        state = seed_u64 & _M64
-        key = []
-        for _ in range(8):  # rand_core::SeedableRng::seed_from_u64 (PCG32 output function)
-            state = (state * 6364136223846793005 + 11634580027462260723) & _M64
-            xorshifted = (((state >> 18) ^ state) >> 27) & _M32
-            rot = state >> 59
-            key.append(((xorshifted >> rot) | (xorshifted << ((32 - rot) & 31))) & _M32)
+    def __init__(self, seed_u64=None, key_words=None):
+        if key_words is not None:  # SeedableRng::from_seed: eight little-endian key words
+            key = [int(w) & _M32 for w in key_words]
+        else:
+            state = seed_u64 & _M64
+            key = []
+            for _ in range(8):  # rand_core::SeedableRng::seed_from_u64 (PCG32 output function)
+                state = (state * 6364136223846793005 + 11634580027462260723) & _M64
+                key.append(_pcg32_output(state))
         self.key, self.counter, self.buf, self.idx = key, 0, [], 16
 
     def _block(self):
@@ -59,20 +93,16 @@ class ChaCha12Rng:
         self.idx += 1
         return v
 
-    def random_range_u32(self, bound):
-        """UniformInt<u32>::sample_single_inclusive(0, bound - 1): Canon's method, one retry."""
-        m = self.next_u32() * bound
-        result, lo = m >> 32, m & _M32
-        if lo > ((-bound) & _M32):
-            new_hi = (self.next_u32() * bound) >> 32
-            result += 1 if lo + new_hi > _M32 else 0
-        return result
 
 
 def shuffle_seeded_perm(seed: int, length: int) -> np.ndarray:
+    return shuffle_perm_with(ChaCha12Rng(seed), length)
+
+
+def shuffle_perm_with(rng, length: int) -> np.ndarray:
+    """SliceRandom::shuffle of [0, length) over any generator with next_u32 / random_range_u32."""
     perm = list(range(length))
     if length > 1:
-        rng = ChaCha12Rng(seed)
         n, chunk, chunk_remaining = 0, 0, 1  # IncreasingUniform::new(rng, 0)
         for i in range(length):
             next_n = n + 1
