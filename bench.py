@@ -118,7 +118,7 @@ def pmc_entry(kernel, num_vars, mode):
         return None
 
 
-def commit_moved_bytes(per, row_len, cw, depth, cols):
+def commit_moved_bytes(per, row_len, cw, depth, cols, direct=False):
     """Bytes the commit kernel really moves per launch (as opposed to SURVEY 8d's full-materialisation figure): the
     witness, 16-byte row entries (the 96 significant bits + sign; Int<4> only on demand), the tree nodes, the
     children of levels >= 4 read back by the in-kernel upper levels, the roots.  cols = the opening hint (None: plain
@@ -133,6 +133,8 @@ def commit_moved_bytes(per, row_len, cw, depth, cols):
         n1 = np.unique((c >> 1) ^ 1).size
         n2 = np.unique((c >> 2) ^ 1).size
         per_row = 16 * c.size + 32 * (n0 + n1 + n2 + upper_nodes)
+        if direct:  # zip_commit_open: value (32 B) + three siblings per OPENING, written into the proof
+            per_row = len(cols) * (32 + 3 * 32) + 32 * upper_nodes
     return int(per * (row_len * 8 + per_row + reread + 32))
 
 
@@ -151,6 +153,8 @@ def main():
     ap.add_argument("--num-vars", type=int, default=24)
     ap.add_argument("--shard", choices=["polys", "rows"], default="polys")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-calls", action="store_true",
+                    help="zip_commit_hinted + zip_open instead of zip_commit_open (values / low siblings via the trees)")
     ap.add_argument("--no-hint", action="store_true",
                     help="plain zip_commit (every row entry and tree node stored) instead of zip_commit_hinted")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5A494E43)
@@ -223,10 +227,14 @@ def main():
             com, _roots = sharded.commit(evals_d)
             sharded.open(com, evals_d, coeffs, cols, q0, zf)
         else:
-            # asynchronous: the open below overlaps it.  The columns are known before the commit, as in the prover
-            # flow (fresh PcsTranscript, src/zinc/prover.rs:316): the commit kernel skips the stores they never read
-            com, _ = ctx.commit(evals_d, want_roots=False, hint_cols=None if args.no_hint else cols)
-            com.open(evals_d, coeffs, cols, q0, zf, out=proof)  # returns when the whole stream is in HBM
+            if args.two_calls or args.no_hint:
+                # asynchronous: the open below overlaps it.  --no-hint: plain zip_commit, everything stored
+                com, _ = ctx.commit(evals_d, want_roots=False, hint_cols=None if args.no_hint else cols)
+                com.open(evals_d, coeffs, cols, q0, zf, out=proof)  # returns when the whole stream is in HBM
+            else:
+                # commit + open as ONE call, as the prover makes them (commit_z_mle_and_prove_evaluation opens with
+                # a fresh PcsTranscript, src/zinc/prover.rs:305-328: the columns are known before the commit)
+                _, _, com = ctx.commit_open(evals_d, coeffs, cols, q0, zf, out=proof, want_roots=False, keep=True)
             if world > 1:
                 # the one exchange of the commit: every rank's Merkle roots
                 roots_ptr = com.roots_ptr()  # rows=NULL: the 16-byte row entries are not expanded
@@ -270,8 +278,10 @@ def main():
         avg_ms = tot_ms / launches
         commit_bytes = per * row_len * 8 + per * cw * 32 * 3
         achieved = commit_bytes / (avg_ms * 1e-3) / 1e9
-        mode = "plain" if args.no_hint else "hinted"
-        moved = commit_moved_bytes(per, row_len, cw, depth, None if args.no_hint else cols)
+        direct = (not args.no_hint and not args.two_calls and 512 <= cw <= 8192
+                  and os.environ.get("ZIP_HIP_DIRECT") == "1")  # commit_supports_direct (zip_hip.hip)
+        mode = "plain" if args.no_hint else "direct" if direct else "hinted"
+        moved = commit_moved_bytes(per, row_len, cw, depth, None if args.no_hint else cols, direct)
         pe = pmc_entry(dom, nv, mode) if not rows_mode else None
         traffic = int((2 * pe["fetch_kib"] + pe["write_kib"]) * 1024) if pe else None  # reads x2: profiles/*_fetch_calibration.md
         simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
@@ -302,9 +312,13 @@ def main():
             "config": {"workload": "Zip commit+open_z 2^%d coeffs (BASELINE %s)" % (nv, configs_idx), "row_len": row_len,
                        "num_rows": num_rows, "codeword_len": cw, "column_openings": n_cols, "field_limbs": fl,
                        "parallelism": ("rows%d" % world if rows_mode else "polys%d" % world),
-                       "commit": ("zip_commit (everything stored)" if args.no_hint else
-                                  "zip_commit_hinted (the 1000 columns are known before the commit, prover.rs:316; "
-                                  "stores no opening reads are skipped)")},
+                       "commit": ("zip_commit + zip_open (everything stored)" if args.no_hint else
+                                  "zip_commit_hinted + zip_open (the 1000 columns are known before the commit, "
+                                  "prover.rs:316; stores no opening reads are skipped)" if args.two_calls else
+                                  "zip_commit_open (one call, as commit_z_mle_and_prove_evaluation: the 1000 columns are "
+                                  "known before the commit, prover.rs:316; stores no opening reads are skipped%s)"
+                                  % ("; ZIP_HIP_DIRECT=1: values and the three lowest siblings go straight into the proof"
+                                     if direct else ""))},
             # the contract's HBM figure for the dominant kernel: SURVEY 8d algorithmic bytes / its launch time / 8 TB/s ...
             "roofline": {"bound": "valu", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -316,7 +330,8 @@ def main():
                                  "not what binds this kernel (roofline_valu).  `achieved` prices SURVEY 8d's full "
                                  "materialisation (200 B/coeff); `moved_bytes_per_launch` is what this build stores "
                                  "(16-byte row entries%s); `traffic` = FETCH_SIZE x2 + WRITE_SIZE of the committed PMC pass"
-                                 % (per * (2 * cw - 1) / 1e6, "" if args.no_hint else ", only what the hinted openings read")},
+                                 % (per * (2 * cw - 1) / 1e6, "" if args.no_hint else ", only what the hinted openings read"
+                                    + (", the values and three lowest siblings of every opening straight into the proof" if direct else ""))},
             # ... and the roofline that does bind it
             "roofline_valu": valu,
             "roofline_gather": {"bound": "hbm", "kernel": "open_columns_kernel",

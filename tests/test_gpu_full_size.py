@@ -1,6 +1,8 @@
 """BASELINE.json's full sizes on the GPU, checked through size-independent properties and sampled
 rows (the oracle cannot redo 2^24 in test time): sampled encoded rows / trees / roots against the
 oracle, exact proof length, the oracle's verifier accepting the 1.74 GiB proof, linearity."""
+import os
+
 import numpy as np
 import pytest
 
@@ -78,6 +80,22 @@ def test_commit_open_2pow24(env):
     bad = proof.copy()
     bad[proof.size // 2] ^= 1
     assert z.verify(f, roots, point, ev, bad, check_merkle=True) != 0
+
+    # zip_commit_open, both variants: the same 1.74 GiB, byte for byte (poisoned buffer first)
+    d_ref = torch.from_numpy(proof).cuda()
+    for direct in ("0", "1"):
+        os.environ["ZIP_HIP_DIRECT"] = direct
+        try:
+            d_one = torch.full((proof.size,), 0x33, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()  # the fill runs on torch's stream, the library on its own
+            _, roots_one, _ = ctx.commit_open(d_evals, coeffs, cols, q0, cabi.make_field(BENCH_MODULUS, 4), out=d_one)
+            ctx.synchronize()
+        finally:
+            os.environ.pop("ZIP_HIP_DIRECT", None)
+        assert np.array_equal(roots_one, roots)
+        assert torch.equal(d_one, d_ref), direct
+        del d_one
+    del d_ref
 
     # the device verifier (zip_verify) agrees with the oracle's on the full-size stream, and the witness
     # MLE evaluation (prover.rs:317-319) equals the oracle's
@@ -211,10 +229,11 @@ def test_commit_open_2pow26_full_on_one_gpu(env):
     com2.free()
 
 
-@pytest.mark.parametrize("hinted", [False, True])
-def test_commit_open_2pow22_pipelined_gather_byte_diff(env, hinted):
+@pytest.mark.parametrize("hinted", [False, True, "one_call", "one_call_direct"])
+def test_commit_open_2pow22_pipelined_gather_byte_diff(env, hinted, monkeypatch):
     """2^22 with the default chunking (two chunks: the gather of the first runs beside the hashing of the second):
-    sampled proof blocks byte for byte against oracle-built rows and paths, with and without the opening hint."""
+    sampled proof blocks byte for byte against oracle-built rows and paths -- plain commit, hinted commit, and
+    zip_commit_open (low part of every opening written by the commit kernel)."""
     cabi, torch = env
     nv = 22
     z = orc.Zip(nv)
@@ -224,9 +243,14 @@ def test_commit_open_2pow22_pipelined_gather_byte_diff(env, hinted):
     coeffs, cols, point, q0, q1 = _squeeze_open_inputs(z, f, nv)
     ctx = cabi.ZipContext(nv, z.perm1, z.perm2)
     d_evals = torch.from_numpy(evals).cuda()
-    proof = torch.empty(ctx.proof_len(1000, 4), dtype=torch.uint8, device="cuda")
-    com, _ = ctx.commit(d_evals, want_roots=False, hint_cols=cols if hinted else None)  # asynchronous
-    com.open(d_evals, coeffs, cols, q0, zf, out=proof)
+    proof = torch.full((ctx.proof_len(1000, 4),), 0x55, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # the fill runs on torch's stream, the library on its own
+    monkeypatch.setenv("ZIP_HIP_DIRECT", "1" if hinted == "one_call_direct" else "0")
+    if hinted in ("one_call", "one_call_direct"):
+        _, _, com = ctx.commit_open(d_evals, coeffs, cols, q0, zf, out=proof, want_roots=False, keep=True)
+    else:
+        com, _ = ctx.commit(d_evals, want_roots=False, hint_cols=cols if hinted else None)  # asynchronous
+        com.open(d_evals, coeffs, cols, q0, zf, out=proof)
     ctx.synchronize()
     _diff_proof_columns(z, evals, proof, cols, [0, 1, 333, 500, 666, 998, 999], [0, 1, 255, 256, 1023, 1024, 2047],
                         z.row_len * 64)

@@ -403,3 +403,50 @@ def test_hinted_commit_opens_bit_exact_and_completes_itself(cabi, geometry):
     com, _ = ctx.commit(evals, hint_cols=cols[:3])
     rows, layers, _ = com.download()
     assert np.array_equal(rows, rows_o) and np.array_equal(layers, layers_o[:, : 2 * z.codeword_len - 2])
+
+
+@pytest.mark.parametrize("geometry", [(16, None), (17, None), (18, None), (20, None), (17, (8192, 16, 16384)), (12, None), (9, None)])
+@pytest.mark.parametrize("device_out", [False, True])
+@pytest.mark.parametrize("direct", ["0", "1"])
+def test_commit_open_in_one_call_is_byte_identical(cabi, geometry, device_out, direct, monkeypatch):
+    """zip_commit_open (the binding for commit_z_mle_and_prove_evaluation, prover.rs:305-328).  ZIP_HIP_DIRECT=1: the
+    commit kernel itself writes the opened values and the three lowest siblings of every path into the proof -- at EVERY
+    place the wire format wants them (at codeword 512 the 1000 squeezed columns repeat, and a level-2 node serves up to
+    four columns) -- and the gather behind it the rest.  Roots and every proof byte equal the oracle's; the output
+    buffer is poisoned first, so a byte nobody wrote shows.  (codeword 128 / 16384: no direct variant, same result.)"""
+    monkeypatch.setenv("ZIP_HIP_DIRECT", direct)
+    nv, geo = geometry
+    z = orc.Zip(nv, geometry=geo) if geo else orc.Zip(nv)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    evals = _witness(nv, seed=31)
+    point = orc.point_to_field(f, np.arange(-7, nv - 7, dtype=np.int64))
+    rows_o, layers_o, roots_o = z.commit(evals)
+    proof_o, cols, coeffs = z.open(f, evals, rows_o, layers_o, point, orc.new_transcript())
+    lr = z.num_rows.bit_length() - 1
+    q0 = orc.build_eq_x_r(f, point[nv - lr:])
+    ctx = _ctx(cabi, z)
+    if device_out:
+        torch = pytest.importorskip("torch")
+        out = torch.full((proof_o.size,), 0xAA, dtype=torch.uint8, device="cuda")
+        d_evals = torch.from_numpy(evals).cuda()
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the library on its own
+        proof, roots, com = ctx.commit_open(d_evals, coeffs, cols, q0, zf, out=out, keep=True)
+        ctx.synchronize()
+        got = proof.cpu().numpy()
+    else:
+        proof, roots, com = ctx.commit_open(evals, coeffs, cols, q0, zf, keep=True)
+        got = proof
+    assert np.array_equal(roots, roots_o)
+    bad = np.flatnonzero(got != proof_o)
+    assert bad.size == 0, f"{bad.size} proof bytes differ, first at {bad[:8]}"
+    # the handle completes itself when asked for what went into the proof instead of into rows / layers
+    rows, layers, roots2 = com.download()
+    assert np.array_equal(rows, rows_o) and np.array_equal(roots2, roots_o)
+    assert np.array_equal(layers, layers_o[:, : 2 * z.codeword_len - 2])
+    again = com.open(evals, coeffs, cols, q0, zf)
+    assert np.array_equal(again, proof_o)
+    com.free()
+    # without keeping the handle
+    proof2, _, none = ctx.commit_open(evals, coeffs, cols, q0, zf, want_roots=False)
+    assert none is None and np.array_equal(proof2, proof_o)

@@ -1,11 +1,7 @@
 #!/bin/bash
 run() { local flags="$1"; shift; echo -n "[$flags] $* : "; env "$@" timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline $flags 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k:v for k,v in d['kernels_ms_per_step'].items() if 'wait' not in k})"; }
-ZIP_HIP_EXP_SKIP_LOW=3 python tools/kernel_times.py --serial --hint --reps 5 | grep -E "commit|open_col"
-python tools/kernel_times.py --serial --hint --reps 5 | grep -E "commit|open_col"
-for i in 1 2; do
+for i in 1 2 3; do
+run "--two-calls" X=0
 run "" X=0
-run "" ZIP_HIP_EXP_SKIP_LOW=3
-run "" ZIP_HIP_EXP_SKIP_LOW=3 ZIP_HIP_CHUNK_ROUNDS=4,4,4,3,1
-run "" ZIP_HIP_EXP_SKIP_LOW=3 ZIP_HIP_CHUNK_ROUNDS=6,4,3,2,1
-run "" ZIP_HIP_EXP_SKIP_LOW=4
+run "" ZIP_HIP_DIRECT=1
 done

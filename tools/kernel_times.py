@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--serial", action="store_true", help="wait for the commit before opening (kernels timed alone)")
     ap.add_argument("--hint", action="store_true", help="zip_commit_hinted with the columns of the open")
-    ap.add_argument("--both", action="store_true", help="alternate hinted and plain commits (PMC passes)")
+    ap.add_argument("--both", action="store_true", help="zip_commit_open, hinted and plain commits in turn (PMC passes)")
     args = ap.parse_args()
     import torch
 
@@ -33,11 +33,14 @@ def main():
     for rep in range(args.reps + 1):
         if rep == 1:
             ctx.set_profiling(True)
-        for hinted in ((True, False) if args.both else (args.hint,)):
-            com, _ = ctx.commit(evals, want_roots=False, hint_cols=cols if hinted else None)
-            if args.serial:
-                ctx.synchronize()
-            com.open(evals, coeffs, cols, q0, zf, out=proof)
+        for hinted in (("one_call", True, False) if args.both else (args.hint,)):
+            if hinted == "one_call":
+                _, _, com = ctx.commit_open(evals, coeffs, cols, q0, zf, out=proof, want_roots=False, keep=True)
+            else:
+                com, _ = ctx.commit(evals, want_roots=False, hint_cols=cols if hinted else None)
+                if args.serial:
+                    ctx.synchronize()
+                com.open(evals, coeffs, cols, q0, zf, out=proof)
             com.free()
         c2, _ = ctx.commit(evals, with_merkle=False)
         c2.free()

@@ -48,13 +48,13 @@ def classify(kernel):
     k = kernel
     if "raa_commit16_kernel<" in k or "raa_commit_kernel<" in k:
         args = k[k.index("<") + 1:k.index(">")].replace(" ", "").split(",")
-        if "raa_commit16" in k:
-            hashed, masked = args[1] == "true", (len(args) > 2 and args[2] == "true")
-        else:
-            hashed, masked = args[1] == "true", (len(args) > 2 and args[2] == "true")
-        if not hashed:
+        if args[1] != "true":  # encode only
             return None
-        return "raa_commit_kernel", "hinted" if masked else "plain"
+        if "raa_commit16" in k:  # <T, HASH, MASKED>
+            mode = "hinted" if (len(args) > 2 and args[2] == "true") else "plain"
+        else:  # <E, HASH, MODE>: 0 everything stored, 1 hinted, 2 direct (zip_commit_open)
+            mode = {"0": "plain", "1": "hinted", "2": "direct"}.get(args[2] if len(args) > 2 else "0", "plain")
+        return "raa_commit_kernel", mode
     if "open_columns_kernel" in k:
         return "open_columns_kernel", "any"
     return None

@@ -25,7 +25,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 
 EXPORTED_SYMBOLS = (
     "zip_abi_version", "zip_strerror", "zip_device_count", "zip_release_cached_memory", "zip_host_register", "zip_host_unregister", "zip_ctx_create", "zip_ctx_destroy",
-    "zip_ctx_last_error", "zip_ctx_synchronize", "zip_ctx_stream", "zip_commit", "zip_commit_hinted", "zip_commitment_free",
+    "zip_ctx_last_error", "zip_ctx_synchronize", "zip_ctx_stream", "zip_commit", "zip_commit_hinted", "zip_commit_open", "zip_commitment_free",
     "zip_commitment_device_ptrs", "zip_commit_download", "zip_commitment_upload", "zip_open_testing",
     "zip_open_columns", "zip_open_eval", "zip_proof_len", "zip_open", "zip_sum_partials", "zip_merkle_trees",
     "zip_ctx_set_profiling", "zip_ctx_profile_read", "zip_ctx_commit_clock", "zip_verify", "zip_mle_eval", "zip_commitment_mle_eval", "zip_field_map_int256",
@@ -135,6 +135,9 @@ def lib():
     L.zip_ctx_stream.restype = vp
     L.zip_commit.argtypes = [vp, i64p, C.c_size_t, C.c_int, C.c_int32, u8p, C.POINTER(vp)]
     L.zip_commit_hinted.argtypes = [vp, i64p, C.c_size_t, C.c_int, u32p, C.c_uint32, u8p, C.POINTER(vp)]
+    L.zip_commit_open.argtypes = [vp, i64p, C.c_size_t, C.c_int, i64p, u32p, C.c_uint32, u64p, C.POINTER(ZipField), u8p, vp,
+                                  C.c_int, C.POINTER(vp)]
+    L.zip_commit_open.restype = C.c_int32
     L.zip_verify.argtypes = [vp, u8p, vp, C.c_int, C.c_size_t, i64p, u32p, C.c_uint32, u64p, u64p, u64p,
                              C.POINTER(ZipField), C.POINTER(VerifyReport)]
     L.zip_mle_eval.argtypes = [vp, i64p, C.c_int, u64p, u64p, C.POINTER(ZipField), u64p]
@@ -299,6 +302,25 @@ class ZipContext:
             rc = lib().zip_commit(self._h, ptr, n, kind, int(with_merkle), rp, C.byref(h))
             self._check(rc, "zip_commit")
         return Commitment(self, h, bool(with_merkle)), roots
+
+    def commit_open(self, evals, coeffs, cols, q0_mont, field, out=None, want_roots=True, keep=False):
+        """zip_commit_open: MultilinearZip::commit + open in one call (prover.rs:305-328).
+        -> (proof, roots or None, Commitment or None)."""
+        ptr, kind = _ptr(evals)
+        n = evals.size if isinstance(evals, np.ndarray) else evals.numel()
+        cols = np.ascontiguousarray(cols, dtype=np.uint32)
+        coeffs_c = np.ascontiguousarray(coeffs, dtype=np.int64) if coeffs is not None else None
+        q0 = np.ascontiguousarray(q0_mont, dtype=np.uint64) if q0_mont is not None else None
+        roots = np.zeros((self.rows_local, 32), dtype=np.uint8) if want_roots else None
+        res = out if out is not None else np.zeros(self.proof_len(cols.size, field.limbs), dtype=np.uint8)
+        optr, okind = _ptr(res)
+        h = C.c_void_p()
+        rc = lib().zip_commit_open(self._h, ptr, n, kind, coeffs_c.ctypes.data if coeffs_c is not None else None,
+                                   cols.ctypes.data, cols.size, q0.ctypes.data if q0 is not None else None, C.byref(field),
+                                   roots.ctypes.data if roots is not None else None, optr, okind,
+                                   C.byref(h) if keep else None)
+        self._check(rc, "zip_commit_open")
+        return res, roots, (Commitment(self, h, True) if keep else None)
 
     def upload_commitment(self, rows, layers=None, roots=None):
         # keep every (possibly copied) array alive across the call

@@ -111,6 +111,7 @@ struct zip_commitment {
     // set (bit c = column c was hinted); anything else asked of the handle first re-runs the commit in full
     // (rematerialize) from the witness: `evals` above, or the caller's device array `evals_ref`.
     bool hinted = false;
+    bool direct = false;  // zip_commit_open: values and level-0..2 siblings went into the proof, not into rows / layers
     std::vector<uint32_t> hint_cols;
     unsigned char *hint_h = nullptr;  // pinned staging of the bitmaps (returns to ctx->hint_free)
     uint32_t *need_d = nullptr;       // device bitmaps (CommitArgs.need)
@@ -648,12 +649,17 @@ int32_t ensure_dynamic_lds(zip_ctx *ctx, const void *kern, size_t bytes) {
 }
 
 // ------------------------------------------------------------------ commit dispatch
+// LDS of the per-lane destination lists of the direct commit kernel: four u16 entries per opening
+size_t direct_lds_bytes(uint32_t n_cols) { return ((size_t)n_cols * 8 + 15) & ~(size_t)15; }
+// bytes of CommitArgs.open_tab: vp[cw / 32] (u64) | firstr[n_cols] | next[n_cols] (u16), rounded to 16
+size_t direct_table_bytes(uint32_t cw, uint32_t n_cols) { return ((size_t)cw / 32 * 8 + (size_t)n_cols * 4 + 15) & ~(size_t)15; }
 // Persistent launch: as many workgroups as stay resident together (at most one per row).
-template <int E, bool HASH, bool MASKED = false>
+template <int E, bool HASH, int MODE = kStoreAll>
 int32_t launch_commit(zip_ctx *ctx, const CommitArgs &a, uint32_t threads, uint32_t grid, hipStream_t st) {
-    // wave totals + E planes of (threads + 32/E) slots of 12 bytes + the witness row
-    const size_t lds = 512 + (size_t)E * (threads + 32 / E) * 12 + (size_t)a.row_len * 8;
-    auto kern = raa_commit_kernel<E, HASH, MASKED>;
+    // wave totals + E planes of (threads + 32/E) slots of 12 bytes + the witness row (+ the opening tables)
+    size_t lds = 512 + (size_t)E * (threads + 32 / E) * 12 + (size_t)a.row_len * 8;
+    if (MODE == kStoreDirect) lds += direct_lds_bytes(a.n_open);
+    auto kern = raa_commit_kernel<E, HASH, MODE>;
     if (int32_t rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
     LaunchTimer t(ctx, HASH ? "raa_commit_kernel" : "raa_encode_kernel", st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
@@ -706,17 +712,41 @@ uint32_t commit_wgs_per_cu(const CommitGeom &g) {
 
 // geometries whose commit kernel has a hint-masked variant (smaller ones store everything: the hint is dropped)
 bool commit_supports_hint(uint32_t cw) { return cw >= 512; }
-constexpr size_t kHintBytes = 8192;  // >= 4 * ((cw + 31) / 32 * 2 + cw / 64 + cw / 128 + 2) for cw <= 16384
+// one pinned / device block per hinted commit: the bitmaps (<= 5.6 KB for cw <= 16384) at offset 0, the
+// column -> openings tables of zip_commit_open (first[cw] | next[n_cols], u16) at kHintTables
+constexpr size_t kHintTables = 8192, kHintBytes = kHintTables + 8 * (8192 / 32) + 4 * 4096 + 64;
+constexpr uint32_t kDirectMaxCols = 4096;
+// zip_commit_open writes the low part of the openings from the commit kernel where that kernel has the variant
+// (8 entries per thread) and room in LDS for the tables; elsewhere it is zip_commit_hinted + the whole gather
+bool commit_supports_direct(const zip_ctx *ctx, uint32_t n_cols) {
+    const uint32_t cw = ctx->p.codeword_len;
+    // Opt-in (ZIP_HIP_DIRECT=1).  Measured at 2^24: the gather's time falls from 1.25-1.45 to 0.9 ms per step and its
+    // HBM traffic by a third, but the commit kernel pays 0.15 ms for the scattered stores (one memory-pipeline pass
+    // per store instruction whatever the number of active lanes) and is the critical path: 2.05-2.09 ms per step
+    // against 2.00-2.10 for zip_commit_hinted + the whole gather.  Kept for streams that are HBM-bound beside it.
+    { const char *e = getenv("ZIP_HIP_DIRECT"); if (!e || atoi(e) != 1) return false; }
+    if (ctx->rows_local != ctx->p.num_rows || n_cols == 0 || n_cols > kDirectMaxCols) return false;
+    if (cw < 512 || cw > 8192 || ctx->depth < 3) return false;
+    const CommitGeom g = commit_geom(cw, ctx->p.row_len);
+    if (g.e != 8) return false;
+    // (24-bit multiply and 32-bit offsets in the kernel's store addresses)
+    const uint64_t per_col = (uint64_t)ctx->p.num_rows * (32 + 8 + 32 * (uint64_t)ctx->depth);
+    if ((per_col >> 3) >= (1u << 24) || per_col * n_cols >= ((uint64_t)1 << 35)) return false;
+    return g.lds + direct_lds_bytes(n_cols) + 64 <= 160u * 1024u;
+}
 
 template <bool HASH>
 int32_t dispatch_commit(zip_ctx *ctx, CommitArgs a, uint32_t grid, hipStream_t st) {
     const CommitGeom g = commit_geom(a.cw, a.row_len);
     a.nact = a.cw / g.e < g.threads ? a.cw / g.e : g.threads;
     if (HASH && a.need) {  // opening hint: only the two big geometries have a masked variant (commit_supports_hint)
+        if (g.e == 8 && a.open_cols) return launch_commit<8, HASH, HASH ? kStoreDirect : kStoreAll>(ctx, a, g.threads, grid, st);
+        a.open_cols = nullptr;
         if (g.e == 16) return launch_commit16<HASH, HASH>(ctx, a, grid, st);
-        if (g.e == 8) return launch_commit<8, HASH, HASH>(ctx, a, g.threads, grid, st);
+        if (g.e == 8) return launch_commit<8, HASH, HASH ? kStoreHinted : kStoreAll>(ctx, a, g.threads, grid, st);
         a.need = nullptr;
     }
+    a.open_cols = nullptr;
     switch (g.e) {
         case 16: return launch_commit16<HASH>(ctx, a, grid, st);
         case 8: return launch_commit<8, HASH>(ctx, a, g.threads, grid, st);
@@ -908,7 +938,7 @@ int32_t check_cols(zip_ctx *ctx, const uint32_t *cols_h, uint32_t n_cols) {
 
 // cols_dv: DEVICE pointer (already staged).  Emits the openings of rows [row_lo, row_hi).
 int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d,
-                         uint32_t row_lo, uint32_t row_hi) {
+                         uint32_t row_lo, uint32_t row_hi, uint32_t skip_low = 0) {
     zip_ctx *ctx = c->ctx;
     if (n_cols == 0 || row_hi <= row_lo) return ZIP_OK;
     OpenColsArgs a{};
@@ -932,7 +962,9 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
         rpb = knob_rpb & ~1u;  // even; the value copy needs <= 128
     } else {
         const CommitGeom cg = commit_geom(ctx->p.codeword_len, ctx->p.row_len);
-        const size_t used = (size_t)commit_wgs_per_cu(cg) * cg.lds, rec = 8 + 32 * (size_t)ctx->depth;
+        size_t used = (size_t)commit_wgs_per_cu(cg) * cg.lds;
+        const size_t rec = 8 + 32 * (size_t)(ctx->depth - skip_low);  // bytes of one record in the LDS image
+        if (skip_low) used += direct_lds_bytes(n_cols);  // zip_commit_open: the destination lists in LDS
         const size_t free_lds = used < 160u * 1024u ? 160u * 1024u - used : 0;
         // (2.5 KB of slack: LDS is handed out in granules -- 24 records = 10.7 KB did NOT get in beside 148.8 KB)
         while (rpb > 8 && rpb * rec + 2560 > free_lds) rpb -= 8;
@@ -940,9 +972,8 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
     a.rows_per_block = (row_hi - row_lo) < rpb ? (row_hi - row_lo) : rpb;
     static const int knob_prio = getenv("ZIP_HIP_GATHER_PRIO") ? atoi(getenv("ZIP_HIP_GATHER_PRIO")) : 1;
     a.prio = (uint32_t)knob_prio;
-    static const uint32_t knob_skip = getenv("ZIP_HIP_EXP_SKIP_LOW") ? (uint32_t)atoi(getenv("ZIP_HIP_EXP_SKIP_LOW")) : 0u;
-    a.exp_skip_low = knob_skip;
-    const size_t lds = (size_t)a.rows_per_block * (8 + 32 * (size_t)ctx->depth);
+    a.skip_low = skip_low;
+    const size_t lds = (size_t)a.rows_per_block * (8 + 32 * (size_t)(ctx->depth - skip_low));
     const dim3 grid(n_cols, (row_hi - row_lo + a.rows_per_block - 1) / a.rows_per_block), block(256);
     LaunchTimer t(ctx, "open_columns_kernel");
     if (2 * ctx->depth + 1 <= 32)
@@ -955,12 +986,13 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
 
 // All chunks, each gated on the arrival counter of the (possibly still running) persistent
 // commit kernel: the memory-bound gather of chunk k runs beside the hashing of later chunks.
-int32_t run_open_columns_pipelined(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d) {
+int32_t run_open_columns_pipelined(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d,
+                                   uint32_t skip_low = 0) {
     zip_ctx *ctx = c->ctx;
     if (!c->chunk_done) {
         int32_t rc = wait_ready(c, ctx->stream);
         if (rc) return rc;
-        return run_open_columns(c, cols_dv, n_cols, out_d, 0, ctx->rows_local);
+        return run_open_columns(c, cols_dv, n_cols, out_d, 0, ctx->rows_local, skip_low);
     }
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, c->zeroed, 0));
     // test hook: an unreachable target and a 1 ms limit exercise the recovery path of a timed-out wait
@@ -973,7 +1005,7 @@ int32_t run_open_columns_pipelined(zip_commitment *c, const uint32_t *cols_dv, u
                                force_timeout ? 100000ull : 25000000ull /* 0.25 s at 100 MHz */);
             HIP_TRY(ctx, hipGetLastError());
         }
-        int32_t rc = run_open_columns(c, cols_dv, n_cols, out_d, c->bounds[k], c->bounds[k + 1]);
+        int32_t rc = run_open_columns(c, cols_dv, n_cols, out_d, c->bounds[k], c->bounds[k + 1], skip_low);
         if (rc) return rc;
     }
     return ZIP_OK;
@@ -987,14 +1019,15 @@ size_t column_bytes(const zip_ctx *ctx) {
 // kernel could not run -- which happens when something serialises kernel dispatch across streams
 // (rocprofv3 counter collection does, and may run the waiter first).  The gathers behind that wait
 // read rows that did not exist yet, so the whole gather is redone once the commit has really finished.
-int32_t recover_gather_timeout(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d) {
+int32_t recover_gather_timeout(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d,
+                               uint32_t skip_low = 0) {
     zip_ctx *ctx = c->ctx;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (!(ctx->timeout_flag_h && *ctx->timeout_flag_h)) return ZIP_OK;
     *ctx->timeout_flag_h = 0;
     int32_t rc = wait_ready(c, ctx->stream);
     if (rc) return rc;
-    if ((rc = run_open_columns(c, cols_dv, n_cols, out_d, 0, ctx->rows_local))) return rc;
+    if ((rc = run_open_columns(c, cols_dv, n_cols, out_d, 0, ctx->rows_local, skip_low))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ZIP_OK;
 }
@@ -1565,9 +1598,11 @@ int32_t zip_ctx_synchronize(zip_ctx *ctx) {
 
 void *zip_ctx_stream(zip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+// open_cols_d != nullptr (zip_commit_open): device address of the column openings inside the proof being written;
+// the commit kernel then puts the values and level-0..2 siblings of the hinted columns there (CommitArgs.open_cols).
 static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
                            int32_t with_merkle, const uint32_t *hint_cols, uint32_t n_hint, uint8_t *roots_out,
-                           zip_commitment **out) {
+                           zip_commitment **out, uint8_t *open_cols_d = nullptr) {
     if (!ctx || !out) return ZIP_ERR_NULL;
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1696,11 +1731,43 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
                 n2[s2 >> 5] |= 1u << (s2 & 31);
             }
             c->hint_cols.assign(nv, nv + wv);
+            size_t upload = words * 4;
+            const bool direct = open_cols_d && commit_supports_direct(ctx, n_hint);
+            if (direct) {
+                // column -> openings lists (CommitArgs.open_tab): vp[cw / 32] | firstr[n] | next[n]
+                uint64_t *vp = reinterpret_cast<uint64_t *>(c->hint_h + kHintTables);
+                uint16_t *firstr = reinterpret_cast<uint16_t *>(vp + cw / 32), *next = firstr + n_hint;
+                std::vector<uint16_t> first_of(cw, 0xFFFF);
+                for (uint32_t i = n_hint; i-- > 0;) {  // backwards: the lists come out in opening order
+                    next[i] = first_of[hint_cols[i]];
+                    first_of[hint_cols[i]] = (uint16_t)i;
+                }
+                uint32_t rank = 0;
+                for (uint32_t w = 0; w < cw / 32; w++) {
+                    vp[w] = ((uint64_t)rank << 32) | nv[w];
+                    for (uint32_t b = 0; b < 32; b++)
+                        if ((nv[w] >> b) & 1u) firstr[rank++] = first_of[w * 32 + b];
+                }
+                for (uint32_t k = rank; k < n_hint; k++) firstr[k] = 0xFFFF;
+                upload = kHintTables + direct_table_bytes(cw, n_hint);
+            }
             if ((rc = pool_alloc(ctx, kHintBytes, (void **)&c->need_d))) break;
-            e = hipMemcpyAsync(c->need_d, bm, words * 4, hipMemcpyHostToDevice, ctx->s_commit);
+            e = hipMemcpyAsync(c->need_d, bm, upload, hipMemcpyHostToDevice, ctx->s_commit);
             if (e != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "hint upload failed: %s", hipGetErrorString(e)); break; }
             a.need = c->need_d;
             c->hinted = true;
+            if (direct) {
+                const uint32_t rec = 8 + 32 * ctx->depth;
+                a.open_cols = open_cols_d;
+                a.per_col = (uint64_t)R * (32 + rec);
+                a.rec_bytes = rec;
+                a.rows_total = R;
+                a.n_open = n_hint;
+                static const uint32_t exp_direct = getenv("ZIP_HIP_EXP_DIRECT") ? (uint32_t)atoi(getenv("ZIP_HIP_EXP_DIRECT")) : 0u;
+                a.exp_flags = exp_direct;
+                a.open_tab = reinterpret_cast<const uint64_t *>(reinterpret_cast<const unsigned char *>(c->need_d) + kHintTables);
+                c->direct = true;
+            }
         }
         if (with_merkle && nch > 1) {
             if ((rc = pool_alloc(ctx, (size_t)nch * 4, (void **)&c->chunk_done))) break;
@@ -1762,6 +1829,7 @@ static int32_t rematerialize(zip_commitment *c) {
     zip_ctx *ctx = c->ctx;
     CommitArgs a = c->args;
     a.need = nullptr;
+    a.open_cols = nullptr;
     a.clock = nullptr;
     a.chunk_done = nullptr;  // the chunks of the first run stay published
     a.evals = c->evals ? c->evals : c->evals_ref;
@@ -1772,12 +1840,14 @@ static int32_t rematerialize(zip_commitment *c) {
     if (c->done) HIP_TRY(ctx, hipEventRecord(c->done, ctx->s_commit));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->s_commit));
     c->hinted = false;
+    c->direct = false;
     return ZIP_OK;
 }
 
 // every column of cols[] lies inside the hint (host check); otherwise the handle is completed first
 static int32_t ensure_columns(zip_commitment *c, const uint32_t *cols, uint32_t n_cols) {
     if (!c->hinted) return ZIP_OK;
+    if (c->direct) return rematerialize(c);  // the low levels of the hinted columns only exist in that call's proof
     for (uint32_t i = 0; i < n_cols; i++) {
         const uint32_t col = cols[i];
         if ((col >> 5) >= c->hint_cols.size() || !((c->hint_cols[col >> 5] >> (col & 31)) & 1u)) return rematerialize(c);
@@ -2029,41 +2099,20 @@ size_t zip_proof_len(const zip_ctx *ctx, uint32_t n_cols, uint32_t field_limbs) 
     return len;
 }
 
-int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kind, const int64_t *coeffs,
-                 const uint32_t *cols, uint32_t n_cols, const uint64_t *q0_mont, const zip_field *field,
-                 uint8_t *proof_out, zip_mem_kind out_kind) {
-    if (!c || !proof_out || (n_cols && !cols)) return ZIP_ERR_NULL;
+// The body of MultilinearZip::open with everything on the device: row combinations, column openings (pipelined behind
+// the commit kernel), evaluation row -> out_d.  skip_low != 0: the values and the siblings below that level are already
+// in out_d (zip_commit_open).  Returns after the stream has drained (the small host inputs have been consumed).
+static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int64_t *coeffs, const uint32_t *cols,
+                           uint32_t n_cols, const uint64_t *q0_mont, const HostField &hf, uint8_t *out_d,
+                           uint32_t skip_low) {
     zip_ctx *ctx = c->ctx;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
-    if (ctx->rows_local != ctx->p.num_rows)
-        return fail(ctx, ZIP_ERR_INVALID_PARAM, "zip_open needs an unsharded ctx; use the per-phase calls on a row shard");
-    if (!c->layers) return fail(ctx, ZIP_ERR_INVALID_PARAM, "commitment has no Merkle trees (commit_no_merkle)");
-    HostField hf;
     int32_t rc;
-    if ((rc = make_field(ctx, field, &hf))) return rc;
     const bool single = ctx->p.num_rows == 1;
-    if (!single && (!coeffs || !q0_mont)) return fail(ctx, ZIP_ERR_NULL, "coeffs / q0_mont is NULL");
-    Scratch ev(ctx), res(ctx);
-    const int64_t *evals_d = c->evals;  // witness retained by a host-side commit
-    if (evals) {
-        if ((rc = stage_evals(ctx, evals, evals_kind, (size_t)ctx->rows_local * ctx->p.row_len, ev, &evals_d))) return rc;
-    } else if (!evals_d) {
-        return fail(ctx, ZIP_ERR_NULL, "evals is NULL and the commitment retains no witness");
-    }
-    const size_t total = zip_proof_len(ctx, n_cols, hf.fl);
-    uint8_t *out_d = proof_out;
-    if (out_kind == ZIP_MEM_HOST) {
-        if ((rc = res.get(total))) return rc;
-        out_d = res.as<uint8_t>();
-    }
     const size_t u_bytes = single ? 0 : (size_t)ctx->p.row_len * ctx->p.m_limbs * 8;
     const size_t col_bytes = (size_t)n_cols * column_bytes(ctx);
     CombineOut o{};
     o.uprime = single ? nullptr : reinterpret_cast<uint64_t *>(out_d);
     o.row_be = out_d + u_bytes + col_bytes;
-    if ((rc = check_cols(ctx, cols, n_cols))) return rc;
-    if ((rc = ensure_columns(c, cols, n_cols))) return rc;
     Scratch small(ctx);
     // declared last = destroyed first: on every return path the combination enqueued on s_aux has drained before
     // `small`, `ev` and `res` (its inputs and output) and its own partial sums go back to the pool
@@ -2112,7 +2161,7 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
         HIP_TRY(ctx, hipEventRecord(combined, ctx->s_aux));
     }
     if ((rc = run_open_columns_pipelined(c, reinterpret_cast<const uint32_t *>(sb + si.off[2]), n_cols,
-                                         out_d + u_bytes)))
+                                         out_d + u_bytes, skip_low)))
         return rc;
     if (place == 2) {
         if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o))) return rc;
@@ -2122,9 +2171,89 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, combined, 0));
     }
     // synchronises: the small host inputs (coeffs, cols, q0) have been consumed
-    if ((rc = recover_gather_timeout(c, reinterpret_cast<const uint32_t *>(sb + si.off[2]), n_cols, out_d + u_bytes)))
+    if ((rc = recover_gather_timeout(c, reinterpret_cast<const uint32_t *>(sb + si.off[2]), n_cols, out_d + u_bytes,
+                                     skip_low)))
         return rc;
+    return ZIP_OK;
+}
+
+int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kind, const int64_t *coeffs,
+                 const uint32_t *cols, uint32_t n_cols, const uint64_t *q0_mont, const zip_field *field,
+                 uint8_t *proof_out, zip_mem_kind out_kind) {
+    if (!c || !proof_out || (n_cols && !cols)) return ZIP_ERR_NULL;
+    zip_ctx *ctx = c->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
+    if (ctx->rows_local != ctx->p.num_rows)
+        return fail(ctx, ZIP_ERR_INVALID_PARAM, "zip_open needs an unsharded ctx; use the per-phase calls on a row shard");
+    if (!c->layers) return fail(ctx, ZIP_ERR_INVALID_PARAM, "commitment has no Merkle trees (commit_no_merkle)");
+    HostField hf;
+    int32_t rc;
+    if ((rc = make_field(ctx, field, &hf))) return rc;
+    const bool single = ctx->p.num_rows == 1;
+    if (!single && (!coeffs || !q0_mont)) return fail(ctx, ZIP_ERR_NULL, "coeffs / q0_mont is NULL");
+    Scratch ev(ctx), res(ctx);
+    const int64_t *evals_d = c->evals;  // witness retained by a host-side commit
+    if (evals) {
+        if ((rc = stage_evals(ctx, evals, evals_kind, (size_t)ctx->rows_local * ctx->p.row_len, ev, &evals_d))) return rc;
+    } else if (!evals_d) {
+        return fail(ctx, ZIP_ERR_NULL, "evals is NULL and the commitment retains no witness");
+    }
+    const size_t total = zip_proof_len(ctx, n_cols, hf.fl);
+    uint8_t *out_d = proof_out;
+    if (out_kind == ZIP_MEM_HOST) {
+        if ((rc = res.get(total))) return rc;
+        out_d = res.as<uint8_t>();
+    }
+    if ((rc = check_cols(ctx, cols, n_cols))) return rc;
+    if ((rc = ensure_columns(c, cols, n_cols))) return rc;
+    if ((rc = open_device(c, evals_d, coeffs, cols, n_cols, q0_mont, hf, out_d, 0))) return rc;
     if (out_kind == ZIP_MEM_HOST) return deliver(ctx, proof_out, ZIP_MEM_HOST, out_d, total);
+    return ZIP_OK;
+}
+
+int32_t zip_commit_open(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind, const int64_t *coeffs,
+                        const uint32_t *cols, uint32_t n_cols, const uint64_t *q0_mont, const zip_field *field,
+                        uint8_t *roots_out, uint8_t *proof_out, zip_mem_kind out_kind, zip_commitment **out) {
+    if (!ctx || !proof_out || (n_cols && !cols)) return ZIP_ERR_NULL;
+    if (out) *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
+    if (ctx->rows_local != ctx->p.num_rows)
+        return fail(ctx, ZIP_ERR_INVALID_PARAM, "zip_commit_open needs an unsharded ctx");
+    HostField hf;
+    int32_t rc;
+    if ((rc = make_field(ctx, field, &hf))) return rc;
+    const bool single = ctx->p.num_rows == 1;
+    if (!single && (!coeffs || !q0_mont)) return fail(ctx, ZIP_ERR_NULL, "coeffs / q0_mont is NULL");
+    if ((rc = check_cols(ctx, cols, n_cols))) return rc;
+    const size_t total = zip_proof_len(ctx, n_cols, hf.fl);
+    Scratch res(ctx);
+    uint8_t *out_d = proof_out;
+    if (out_kind == ZIP_MEM_HOST) {
+        if ((rc = res.get(total))) return rc;
+        out_d = res.as<uint8_t>();
+    }
+    const size_t u_bytes = single ? 0 : (size_t)ctx->p.row_len * ctx->p.m_limbs * 8;
+    static const uint32_t none = 0;
+    zip_commitment *c = nullptr;
+    if ((rc = commit_impl(ctx, evals, n_evals, evals_kind, 1, cols ? cols : &none, n_cols, nullptr, &c, out_d + u_bytes)))
+        return rc;
+    const int64_t *evals_d = c->evals ? c->evals : c->evals_ref;
+    rc = open_device(c, evals_d, coeffs, cols, n_cols, q0_mont, hf, out_d, c->direct ? 3u : 0u);
+    if (!rc && roots_out) {
+        rc = wait_ready(c, ctx->stream);
+        if (!rc) rc = deliver(ctx, roots_out, ZIP_MEM_HOST, c->roots, c->roots_bytes);
+    }
+    if (!rc && out_kind == ZIP_MEM_HOST) rc = deliver(ctx, proof_out, ZIP_MEM_HOST, out_d, total);
+    if (rc || !out) {
+        // (the error text of `rc` must survive the calls made while freeing)
+        const std::string keep = ctx->last_error;
+        zip_commitment_free(c);
+        ctx->last_error = keep;
+        return rc;
+    }
+    *out = c;
     return ZIP_OK;
 }
 
