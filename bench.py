@@ -14,7 +14,10 @@ SURVEY.md A.4) are small host arrays handed over inside the timed region.
 N > 1, default `--shard polys` (weak scaling): one process per GPU, every rank commits + opens its
 own 2^24 polynomial (batch_commit / batch_open sharded over ranks, commit.rs:134-142,
 open_z.rs:43-58); the roots of all ranks are all-gathered over RCCL inside the timed region.
-`--shard rows` (strong scaling) row-shards ONE 2^24 polynomial over the ranks (zinc_amd.dist):
+`--shard mctx` (strong scaling): ONE process row-shards ONE polynomial over the N GPUs through the C ABI's
+multi-device context (zip_mctx_commit_open) -- what a Rust ZincProver, one process making one call, can use;
+under torchrun rank 0 works and the other ranks wait at the barriers.
+`--shard rows` (strong scaling, one Python process per GPU): zinc_amd.dist over torch.distributed,
 all-gather of roots and of the partial row combinations + exact on-device sum.
 
 Rank 0 prints ONE JSON line.
@@ -145,13 +148,77 @@ def roots_view(torch, ptr, rows, dev):
     return torch.as_tensor(holder, device=dev)
 
 
+def run_mctx(args, torch, dist, rank, world, cabi, perm1, perm2, zf, coeffs, cols, q0, nv, row_len, num_rows, cw, depth, fl):
+    """--shard mctx: ONE process drives the GPUs through the C ABI's multi-device context (zip_mctx_commit_open): the
+    rows of one polynomial split over them (strong scaling), witness resident on the devices, every output left in
+    HBM (each shard's openings on its own device, u' and the evaluation row on the lead device).  Under torchrun only
+    rank 0 works; the other ranks wait at the barriers.  BENCH_MCTX_DEVICES=0,0,0,0 repeats a device (one-GPU box)."""
+    n = 1 << nv
+    ndev = args.devices or max(world, 1)
+    devs = ([int(x) for x in os.environ["BENCH_MCTX_DEVICES"].split(",")] if "BENCH_MCTX_DEVICES" in os.environ
+            else list(range(ndev)))
+    m = None
+    if rank == 0:
+        m = cabi.ZipMultiContext(nv, perm1, perm2, devs)
+        m.set_witness(splitmix64(args.seed, n))
+
+    def step():
+        if m is not None:
+            m.commit_open(None, coeffs, cols, q0, zf, want_proof=False, want_roots=False)  # returns when every shard has drained
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    if m is not None:
+        m.shard_profile(0, on=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        ktimes = m.shard_profile(0)
+        step_s = dt / args.steps
+        ab = algorithmic_bytes(n, row_len, num_rows, cw, depth, cols.size, fl)
+        per = num_rows // len(devs)
+        launches, tot_ms = ktimes.get("raa_commit_kernel", (1, 0.0))
+        avg_ms = tot_ms / max(launches, 1)
+        commit_bytes = per * row_len * 8 + per * cw * 32 * 3
+        out = {
+            "metric": "Zip commit+open MCoeffs/s at 2^%d witness" % nv, "value": round(n / step_s / 1e6, 2), "unit": "MCoeffs/s",
+            "n_gpus": len(devs), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i64",
+            "data": "synthetic (SplitMix64 full-range i64 witness; coefficient / column / point streams per SURVEY.md 8d)",
+            "config": {"workload": "Zip commit+open_z 2^%d coeffs, ONE polynomial row-sharded over %d device context(s) by one process (zip_mctx)" % (nv, len(devs)),
+                       "row_len": row_len, "num_rows": num_rows, "codeword_len": cw, "column_openings": int(cols.size),
+                       "field_limbs": fl, "parallelism": "mctx rows%d" % len(devs), "devices": devs},
+            "roofline": {"bound": "valu", "kernel": "raa_commit_kernel (shard 0)",
+                         "achieved": round(commit_bytes / (avg_ms * 1e-3) / 1e9, 1) if avg_ms else None, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(commit_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_ms else None,
+                         "traffic": None, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(commit_bytes)},
+            "whole_path": {"algorithmic_bytes": int(sum(ab.values())),
+                           "hbm_frac_per_gpu": round(sum(ab.values()) / step_s / 1e9 / HBM_PEAK_GBS / len(devs), 4)},
+            "kernels_ms_per_step_shard0": {k: round(v[1] / args.steps, 4) for k, v in sorted(ktimes.items())},
+        }
+        print(json.dumps(out), flush=True)
+        m.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--num-vars", type=int, default=24)
-    ap.add_argument("--shard", choices=["polys", "rows"], default="polys")
+    ap.add_argument("--shard", choices=["polys", "rows", "mctx"], default="polys")
+    ap.add_argument("--devices", type=int, default=0, help="--shard mctx: GPUs driven by the one working process (default: --gpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--two-calls", action="store_true",
                     help="zip_commit_hinted + zip_open instead of zip_commit_open (values / low siblings via the trees)")
@@ -205,6 +272,8 @@ def main():
     coeffs, cols, q0 = host_inputs(nv, row_len, num_rows, cw, fl, args.seed)
     n_cols = cols.size
 
+    if args.shard == "mctx":
+        return run_mctx(args, torch, dist, rank, world, cabi, perm1, perm2, zf, coeffs, cols, q0, nv, row_len, num_rows, cw, depth, fl)
     rows_mode = args.shard == "rows" and world > 1
     if rows_mode:
         from zinc_amd.dist import RowShardedZip

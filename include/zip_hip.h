@@ -354,6 +354,40 @@ int32_t zip_commitment_mle_eval(zip_commitment *c, const uint64_t *q0_mont, cons
 int32_t zip_sum_partials(zip_ctx *ctx, const uint64_t *uparts, const uint64_t *fparts, uint32_t n_parts,
                          const zip_field *field, uint64_t *uprime_out, uint64_t *row_out);
 
+/* ---- several GPUs behind one call ---------------------------------------
+ * The reference's callers are one process making one call (src/zinc/prover.rs:305-328): a zip_mctx gives that
+ * process all the GPUs of the node.  It owns one row-shard context per entry of `devices` (contiguous blocks of
+ * rows; an ordinal may repeat -- several shards on one GPU).  `params->device / row_begin / row_count` are ignored.
+ *
+ * zip_mctx_commit_open = zip_commit_open on the whole polynomial, the same roots and the same proof bytes:
+ *   - every shard commits its rows (hinted persistent kernel) and opens THEM for every column, pipelined as on
+ *     one GPU; no shard waits for another;
+ *   - the row combinations are computed per shard and added on the lead device (the first of `devices`): the
+ *     only exchange besides the roots, 96 bytes per witness column and shard, peer copies -- exact, the sums are
+ *     integer / modular;
+ *   - proof_out != NULL (HOST): u', then every shard's rows of every column straight from that shard's memory
+ *     over its own PCIe link (two pitched copies per shard), then the evaluation row.  Pin the buffer
+ *     (zip_host_register) for full link speed;
+ *   - proof_out == NULL: the pieces stay on the devices (zip_mctx_shard_openings, zip_mctx_ends).
+ *   evals      HOST, the whole witness, or NULL to use the slices zip_mctx_set_witness left on the devices
+ *   coeffs, q0_mont, cols   the WHOLE challenge vectors, as for zip_open
+ *   roots_out  HOST, num_rows * 32 bytes, may be NULL */
+typedef struct zip_mctx zip_mctx;
+int32_t zip_mctx_create(const zip_params *params, int32_t n_devices, const int32_t *devices, zip_mctx **out);
+void zip_mctx_destroy(zip_mctx *m);
+const char *zip_mctx_last_error(const zip_mctx *m);
+uint32_t zip_mctx_shards(const zip_mctx *m);
+zip_ctx *zip_mctx_shard_ctx(zip_mctx *m, uint32_t shard); /* the shard's context (profiling hooks, geometry); owned by m */
+int32_t zip_mctx_set_witness(zip_mctx *m, const int64_t *evals, size_t n_evals);
+int32_t zip_mctx_commit_open(zip_mctx *m, const int64_t *evals, const int64_t *coeffs, const uint32_t *cols,
+                             uint32_t n_cols, const uint64_t *q0_mont, const zip_field *field, uint8_t *roots_out,
+                             uint8_t *proof_out);
+/* after zip_mctx_commit_open: shard's openings on ITS device, [n_cols][row_count * 32 B values | row_count records] */
+int32_t zip_mctx_shard_openings(zip_mctx *m, uint32_t shard, uint8_t **ptr, size_t *bytes, uint32_t *row_begin,
+                                uint32_t *row_count);
+/* after zip_mctx_commit_open: u' (u_bytes) followed by the evaluation row (row_bytes) on the lead device */
+int32_t zip_mctx_ends(zip_mctx *m, uint8_t **ptr, size_t *u_bytes, size_t *row_bytes);
+
 /* ---- standalone Merkle tree --------------------------------------------------------
  * MerkleTree::new (pcs/utils.rs:74-85) over num_trees * 2^depth leaves of leaf_limbs
  * (1..8) limbs each.  layers_out: num_trees * ((2<<depth)-1) * 32 B, root last

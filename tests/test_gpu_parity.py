@@ -450,3 +450,39 @@ def test_commit_open_in_one_call_is_byte_identical(cabi, geometry, device_out, d
     # without keeping the handle
     proof2, _, none = ctx.commit_open(evals, coeffs, cols, q0, zf, want_roots=False)
     assert none is None and np.array_equal(proof2, proof_o)
+
+
+@pytest.mark.parametrize("num_vars", [12, 16, 18])
+@pytest.mark.parametrize("shards", [1, 2, 3, 4, 8])
+def test_multi_device_context_proof_equals_unsharded(cabi, num_vars, shards):
+    """zip_mctx (SURVEY 8e behind the C ABI, one process): rows split over `shards` contexts -- here all on device 0,
+    which is what a one-GPU box can run -- every shard commits and opens its rows, the partial row combinations are
+    added on the lead shard, every shard delivers its row slice of every column to the host proof.  Roots and every
+    proof byte equal the oracle's unsharded ones (3 shards: uneven blocks of rows)."""
+    z = orc.Zip(num_vars)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    evals = _witness(num_vars, seed=41)
+    point = orc.point_to_field(f, np.arange(2, num_vars + 2, dtype=np.int64))
+    rows_o, layers_o, roots_o = z.commit(evals)
+    proof_o, cols, coeffs = z.open(f, evals, rows_o, layers_o, point, orc.new_transcript())
+    lr = z.num_rows.bit_length() - 1
+    q0 = orc.build_eq_x_r(f, point[num_vars - lr:])
+    m = cabi.ZipMultiContext(num_vars, z.perm1, z.perm2, [0] * shards)
+    assert m.shards() == shards
+    proof, roots = m.commit_open(evals, coeffs, cols, q0, zf)
+    assert np.array_equal(roots, roots_o)
+    bad = np.flatnonzero(proof != proof_o)
+    assert bad.size == 0, f"{bad.size} proof bytes differ, first at {bad[:8]}"
+    # witness resident on the devices, second call through the same context (buffers reused)
+    m.set_witness(evals)
+    proof2, roots2 = m.commit_open(None, coeffs, cols, q0, zf)
+    assert np.array_equal(roots2, roots_o) and np.array_equal(proof2, proof_o)
+    # a different field width through the same context
+    f2 = orc.make_field(TEST_MODULUS_2, 2)
+    pt2 = orc.point_to_field(f2, np.arange(2, num_vars + 2, dtype=np.int64))
+    proof_o2, cols2, coeffs2 = z.open(f2, evals, rows_o, layers_o, pt2, orc.new_transcript())
+    q02 = orc.build_eq_x_r(f2, pt2[num_vars - lr:])
+    proof3, _ = m.commit_open(None, coeffs2, cols2, q02, cabi.make_field(TEST_MODULUS_2, 2), want_roots=False)
+    assert np.array_equal(proof3, proof_o2)
+    m.close()

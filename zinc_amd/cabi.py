@@ -28,7 +28,9 @@ EXPORTED_SYMBOLS = (
     "zip_ctx_last_error", "zip_ctx_synchronize", "zip_ctx_stream", "zip_commit", "zip_commit_hinted", "zip_commit_open", "zip_commitment_free",
     "zip_commitment_device_ptrs", "zip_commit_download", "zip_commitment_upload", "zip_open_testing",
     "zip_open_columns", "zip_open_eval", "zip_proof_len", "zip_open", "zip_sum_partials", "zip_merkle_trees",
-    "zip_ctx_set_profiling", "zip_ctx_profile_read", "zip_ctx_commit_clock", "zip_verify", "zip_mle_eval", "zip_commitment_mle_eval", "zip_field_map_int256",
+    "zip_ctx_set_profiling", "zip_ctx_profile_read", "zip_ctx_commit_clock",
+    "zip_mctx_create", "zip_mctx_destroy", "zip_mctx_last_error", "zip_mctx_shards", "zip_mctx_shard_ctx", "zip_mctx_set_witness",
+    "zip_mctx_commit_open", "zip_mctx_shard_openings", "zip_mctx_ends", "zip_verify", "zip_mle_eval", "zip_commitment_mle_eval", "zip_field_map_int256",
     "zip_open_stream", "zip_sumcheck_init", "zip_sumcheck_round", "zip_sumcheck_round_begin", "zip_sumcheck_round_end", "zip_sumcheck_last_error", "zip_sumcheck_free",
     "zip_ccs_create", "zip_ccs_free", "zip_ccs_last_error", "zip_ccs_set_z", "zip_ccs_eq_table",
     "zip_ccs_second_table", "zip_ccs_table", "zip_ccs_download", "zip_ccs_eval_matrices",
@@ -183,6 +185,22 @@ def lib():
     L.zip_ctx_profile_read.argtypes = [vp, C.POINTER(KernelTime), C.c_uint32]
     L.zip_ctx_commit_clock.argtypes = [vp, C.POINTER(C.c_double)]
     L.zip_ctx_commit_clock.restype = C.c_int32
+    L.zip_mctx_create.argtypes = [C.POINTER(ZipParams), C.c_int32, C.POINTER(C.c_int32), C.POINTER(vp)]
+    L.zip_mctx_destroy.argtypes = [vp]
+    L.zip_mctx_destroy.restype = None
+    L.zip_mctx_last_error.argtypes = [vp]
+    L.zip_mctx_last_error.restype = C.c_char_p
+    L.zip_mctx_shards.argtypes = [vp]
+    L.zip_mctx_shards.restype = C.c_uint32
+    L.zip_mctx_shard_ctx.argtypes = [vp, C.c_uint32]
+    L.zip_mctx_shard_ctx.restype = vp
+    L.zip_mctx_set_witness.argtypes = [vp, i64p, C.c_size_t]
+    L.zip_mctx_commit_open.argtypes = [vp, i64p, i64p, u32p, C.c_uint32, u64p, C.POINTER(ZipField), u8p, u8p]
+    L.zip_mctx_shard_openings.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),
+                                          C.POINTER(C.c_uint32)]
+    L.zip_mctx_ends.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    for fn in ("zip_mctx_create", "zip_mctx_set_witness", "zip_mctx_commit_open", "zip_mctx_shard_openings", "zip_mctx_ends"):
+        getattr(L, fn).restype = C.c_int32
     for fn in ("zip_ctx_create", "zip_ctx_synchronize", "zip_commit", "zip_commit_hinted", "zip_commitment_device_ptrs",
                "zip_commit_download", "zip_commitment_upload", "zip_open_testing", "zip_open_columns",
                "zip_open_eval", "zip_open", "zip_sum_partials", "zip_merkle_trees", "zip_ctx_set_profiling",
@@ -419,6 +437,77 @@ class ZipContext:
         mhz = C.c_double(0.0)
         self._check(lib().zip_ctx_commit_clock(self._h, C.byref(mhz)), "zip_ctx_commit_clock")
         return mhz.value
+
+
+class ZipMultiContext:
+    """zip_mctx: one polynomial's commit + open over several GPUs from ONE process (devices may repeat)."""
+
+    def __init__(self, num_vars, perm1, perm2, devices, geometry_override=None):
+        row_len, num_rows, cw = geometry_override or geometry(num_vars)
+        self.num_vars, self.row_len, self.num_rows, self.codeword_len = num_vars, row_len, num_rows, cw
+        self.depth = cw.bit_length() - 1
+        p1 = np.ascontiguousarray(perm1, dtype=np.uint32)
+        p2 = np.ascontiguousarray(perm2, dtype=np.uint32)
+        p = ZipParams(num_vars, row_len, num_rows, cw, cw // row_len, 1, 4, 8,
+                      p1.ctypes.data_as(C.POINTER(C.c_uint32)), p2.ctypes.data_as(C.POINTER(C.c_uint32)), 0, 0, 0)
+        devs = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = lib().zip_mctx_create(C.byref(p), len(devices), devs, C.byref(h))
+        if rc:
+            raise ZipError(rc, "zip_mctx_create")
+        self._h = h
+
+    def _check(self, rc, what):
+        if rc:
+            raise ZipError(rc, what, (lib().zip_mctx_last_error(self._h) or b"").decode())
+
+    def proof_len(self, n_cols, fl):
+        u = self.row_len * 64 if self.num_rows > 1 else 0
+        return u + n_cols * self.num_rows * (32 + 8 + 32 * self.depth) + self.row_len * 8 * fl
+
+    def set_witness(self, evals):
+        evals = np.ascontiguousarray(evals, dtype=np.int64)
+        self._check(lib().zip_mctx_set_witness(self._h, evals.ctypes.data, evals.size), "zip_mctx_set_witness")
+
+    def commit_open(self, evals, coeffs, cols, q0_mont, field, want_proof=True, want_roots=True):
+        """evals: host int64 array or None (witness placed with set_witness).  -> (proof or None, roots or None)."""
+        ev = np.ascontiguousarray(evals, dtype=np.int64) if evals is not None else None
+        cols = np.ascontiguousarray(cols, dtype=np.uint32)
+        co = np.ascontiguousarray(coeffs, dtype=np.int64) if coeffs is not None else None
+        q0 = np.ascontiguousarray(q0_mont, dtype=np.uint64) if q0_mont is not None else None
+        proof = np.zeros(self.proof_len(cols.size, field.limbs), dtype=np.uint8) if want_proof else None
+        roots = np.zeros((self.num_rows, 32), dtype=np.uint8) if want_roots else None
+        rc = lib().zip_mctx_commit_open(self._h, ev.ctypes.data if ev is not None else None,
+                                        co.ctypes.data if co is not None else None, cols.ctypes.data, cols.size,
+                                        q0.ctypes.data if q0 is not None else None, C.byref(field),
+                                        roots.ctypes.data if roots is not None else None,
+                                        proof.ctypes.data if proof is not None else None)
+        self._check(rc, "zip_mctx_commit_open")
+        return proof, roots
+
+    def shards(self):
+        return lib().zip_mctx_shards(self._h)
+
+    def shard_profile(self, s, on=None):
+        """Profiling hooks of shard s's context: on=True/False switches, None reads {kernel: (launches, ms)}."""
+        h = lib().zip_mctx_shard_ctx(self._h, s)
+        if on is not None:
+            lib().zip_ctx_set_profiling(h, int(on))
+            return None
+        buf = (KernelTime * 32)()
+        n = lib().zip_ctx_profile_read(h, buf, 32)
+        return {buf[i].name.decode(): (buf[i].launches, buf[i].total_ms) for i in range(max(0, min(n, 32)))}
+
+    def close(self):
+        if self._h:
+            lib().zip_mctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 class Commitment:

@@ -320,7 +320,8 @@ combine_finalize_kernel(FinalizeArgs a, FieldDev<FL> f) {
 template <int FL>
 __global__ void __launch_bounds__(256) sum_partials_kernel(const uint64_t *uparts, const uint64_t *fparts,
                                                            uint32_t G, uint32_t row_len, uint32_t m_limbs,
-                                                           uint64_t *uprime, uint64_t *row_limbs, FieldDev<FL> f) {
+                                                           uint64_t *uprime, uint64_t *row_limbs, FieldDev<FL> f,
+                                                           uint8_t *row_be = nullptr) {
     const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= row_len) return;
     if (uparts) {
@@ -343,8 +344,15 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const uint64_t *upart
             const uint64_t c = add_n<FL>(acc, t);
             if (c || geq_n<FL>(acc, f.modulus)) sub_n<FL>(acc, f.modulus);
         }
+        if (row_limbs) {
 #pragma unroll
-        for (int i = 0; i < FL; i++) row_limbs[(size_t)col * FL + i] = acc[i];
+            for (int i = 0; i < FL; i++) row_limbs[(size_t)col * FL + i] = acc[i];
+        }
+        if (row_be) {  // BigInt::to_bytes_be of the Montgomery value, pcs_transcript.rs:107-113
+            uint64_t *dst = reinterpret_cast<uint64_t *>(row_be + (size_t)col * 8 * FL);
+#pragma unroll
+            for (int i = 0; i < FL; i++) dst[i] = __builtin_bswap64(acc[FL - 1 - i]);
+        }
     }
 }
 

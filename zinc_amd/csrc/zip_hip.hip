@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -2255,6 +2256,312 @@ int32_t zip_commit_open(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_
     }
     *out = c;
     return ZIP_OK;
+}
+
+// =====================================================================================================
+// Several GPUs behind ONE call (single process as the reference's callers are:
+// src/zinc/prover.rs:305-328, benches/zip_benches.rs:100-168).  A zip_mctx owns one row-shard zip_ctx per entry
+// of `devices` (an ordinal may repeat: several shards on one GPU, which is how this is tested on a one-GPU box).
+// Rows are independent until the very end (commit.rs:71-74,172-178), so a commit + open is
+//   per shard   hinted persistent commit of its rows -> roots slice; fused row combinations over its rows
+//               (partial u', partial evaluation row, exact: integer / modular sums are associative); the
+//               openings of ITS rows of every column, pipelined behind its own commit kernel
+//   lead shard  sum of the partial rows (the one exchange besides the 32-byte roots: 96 bytes per column and shard)
+// and the proof stream is assembled where it is wanted: in host memory every shard delivers its row slice of
+// every column over its OWN PCIe link (two pitched copies), which is the point of sharding a path whose
+// single-GPU cost is dominated by moving 1.74 GiB to the host.
+// =====================================================================================================
+struct zip_mctx {
+    std::vector<zip_ctx *> shard;
+    std::vector<int64_t *> witness;      // per shard: its rows of the witness (device), or null
+    std::vector<uint8_t *> slice;        // per shard: [n_cols][count * 32 | count * rec] openings of its rows
+    std::vector<size_t> slice_bytes;
+    std::vector<uint64_t *> upart, fpart;  // per shard: partial u' [row_len][m_limbs], partial row [row_len][fl]
+    std::vector<hipEvent_t> combined;
+    uint64_t *uparts_all = nullptr, *fparts_all = nullptr;  // lead device: [G][...]
+    uint8_t *ends = nullptr;             // lead device: u' (row_len * 64) | evaluation row big-endian (row_len * 8 fl)
+    size_t ends_cap = 0;
+    uint32_t last_cols = 0, last_fl = 0;
+    std::string last_error;
+    std::mutex mu;
+};
+
+static int32_t mfail(zip_mctx *m, int32_t code, const char *what, zip_ctx *from = nullptr) {
+    m->last_error = std::string(what) + (from ? std::string(": ") + from->last_error : std::string());
+    return code;
+}
+
+const char *zip_mctx_last_error(const zip_mctx *m) { return m ? m->last_error.c_str() : ""; }
+uint32_t zip_mctx_shards(const zip_mctx *m) { return m ? (uint32_t)m->shard.size() : 0; }
+zip_ctx *zip_mctx_shard_ctx(zip_mctx *m, uint32_t s) { return (m && s < m->shard.size()) ? m->shard[s] : nullptr; }
+
+void zip_mctx_destroy(zip_mctx *m) {
+    if (!m) return;
+    for (size_t s = 0; s < m->shard.size(); s++) {
+        zip_ctx *ctx = m->shard[s];
+        if (!ctx) continue;
+        (void)hipSetDevice(ctx->device);
+        (void)zip_ctx_synchronize(ctx);
+        if (s < m->witness.size()) pool_release(ctx, m->witness[s]);
+        if (s < m->slice.size()) pool_release(ctx, m->slice[s]);
+        if (s < m->upart.size()) pool_release(ctx, m->upart[s]);
+        if (s < m->fpart.size()) pool_release(ctx, m->fpart[s]);
+        if (s < m->combined.size() && m->combined[s]) (void)hipEventDestroy(m->combined[s]);
+        if (s == 0) {
+            pool_release(ctx, m->uparts_all);
+            pool_release(ctx, m->fparts_all);
+            pool_release(ctx, m->ends);
+        }
+    }
+    for (zip_ctx *ctx : m->shard) zip_ctx_destroy(ctx);
+    delete m;
+}
+
+int32_t zip_mctx_create(const zip_params *p, int32_t n_devices, const int32_t *devices, zip_mctx **out) {
+    if (!p || !out || !devices) return ZIP_ERR_NULL;
+    *out = nullptr;
+    if (n_devices < 1 || (uint32_t)n_devices > p->num_rows || n_devices > 64) return ZIP_ERR_INVALID_PARAM;
+    zip_mctx *m = new (std::nothrow) zip_mctx();
+    if (!m) return ZIP_ERR_ALLOC;
+    const uint32_t G = (uint32_t)n_devices, R = p->num_rows;
+    int32_t rc = ZIP_OK;
+    for (uint32_t s = 0; s < G && !rc; s++) {
+        zip_params ps = *p;
+        ps.device = devices[s];
+        ps.row_begin = (uint32_t)((uint64_t)R * s / G);  // contiguous blocks of rows, as even as they come
+        ps.row_count = (uint32_t)((uint64_t)R * (s + 1) / G) - ps.row_begin;
+        zip_ctx *ctx = nullptr;
+        rc = zip_ctx_create(&ps, &ctx);
+        m->shard.push_back(ctx);
+    }
+    if (!rc) {
+        m->witness.assign(G, nullptr);
+        m->slice.assign(G, nullptr);
+        m->slice_bytes.assign(G, 0);
+        m->upart.assign(G, nullptr);
+        m->fpart.assign(G, nullptr);
+        m->combined.assign(G, nullptr);
+        for (uint32_t s = 0; s < G && !rc; s++) {
+            if (hipSetDevice(m->shard[s]->device) != hipSuccess ||
+                hipEventCreateWithFlags(&m->combined[s], hipEventDisableTiming) != hipSuccess)
+                rc = ZIP_ERR_HIP;
+            // the lead device pulls every shard's partial rows: peer access where the devices differ
+            if (!rc && s > 0 && m->shard[s]->device != m->shard[0]->device) {
+                int can = 0;
+                (void)hipSetDevice(m->shard[0]->device);
+                if (hipDeviceCanAccessPeer(&can, m->shard[0]->device, m->shard[s]->device) == hipSuccess && can) {
+                    hipError_t e = hipDeviceEnablePeerAccess(m->shard[s]->device, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) rc = ZIP_ERR_HIP;
+                    (void)hipGetLastError();
+                }
+            }
+        }
+    }
+    if (rc) {
+        zip_mctx_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return ZIP_OK;
+}
+
+// Places the witness on the devices: shard s gets its rows.  evals: HOST, the whole polynomial.
+int32_t zip_mctx_set_witness(zip_mctx *m, const int64_t *evals, size_t n_evals) {
+    if (!m || !evals) return ZIP_ERR_NULL;
+    std::lock_guard<std::mutex> g(m->mu);
+    const zip_ctx *c0 = m->shard[0];
+    if (n_evals != (size_t)c0->p.num_rows * c0->p.row_len)
+        return mfail(m, ZIP_ERR_SHAPE, "Polynomial has an incorrect number of evaluations for the expected matrix size");
+    for (size_t s = 0; s < m->shard.size(); s++) {
+        zip_ctx *ctx = m->shard[s];
+        if (hipSetDevice(ctx->device) != hipSuccess) return mfail(m, ZIP_ERR_HIP, "hipSetDevice failed");
+        const size_t n = (size_t)ctx->rows_local * ctx->p.row_len;
+        int32_t rc;
+        if (!m->witness[s] && (rc = pool_alloc(ctx, n * 8, (void **)&m->witness[s]))) return mfail(m, rc, "witness slice", ctx);
+        if ((rc = copy_h2d_bounced(ctx, m->witness[s], evals + (size_t)ctx->p.row_begin * ctx->p.row_len, n * 8, ctx->stream)))
+            return mfail(m, rc, "witness upload", ctx);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return mfail(m, ZIP_ERR_HIP, "witness upload failed");
+    }
+    return ZIP_OK;
+}
+
+// Device address and size of shard s's openings after zip_mctx_commit_open: [n_cols][count * 32 bytes of values |
+// count records], its rows of every opened column in wire format (valid until the next call).
+int32_t zip_mctx_shard_openings(zip_mctx *m, uint32_t s, uint8_t **ptr, size_t *bytes, uint32_t *row_begin, uint32_t *row_count) {
+    if (!m || s >= m->shard.size()) return ZIP_ERR_NULL;
+    if (ptr) *ptr = m->slice[s];
+    if (bytes) *bytes = (size_t)m->last_cols * column_bytes(m->shard[s]);
+    if (row_begin) *row_begin = m->shard[s]->p.row_begin;
+    if (row_count) *row_count = m->shard[s]->rows_local;
+    return ZIP_OK;
+}
+// Device address (lead device) of u' (row_len * m_limbs * 8 bytes, absent when num_rows == 1) followed by the
+// evaluation row (row_len * 8 fl bytes, big-endian Montgomery) of the last zip_mctx_commit_open.
+int32_t zip_mctx_ends(zip_mctx *m, uint8_t **ptr, size_t *u_bytes, size_t *row_bytes) {
+    if (!m) return ZIP_ERR_NULL;
+    const zip_ctx *c0 = m->shard[0];
+    if (ptr) *ptr = m->ends;
+    if (u_bytes) *u_bytes = c0->p.num_rows > 1 ? (size_t)c0->p.row_len * c0->p.m_limbs * 8 : 0;
+    if (row_bytes) *row_bytes = (size_t)c0->p.row_len * m->last_fl * 8;
+    return ZIP_OK;
+}
+
+int32_t zip_mctx_commit_open(zip_mctx *m, const int64_t *evals, const int64_t *coeffs, const uint32_t *cols,
+                             uint32_t n_cols, const uint64_t *q0_mont, const zip_field *field, uint8_t *roots_out,
+                             uint8_t *proof_out) {
+    if (!m || (n_cols && !cols)) return ZIP_ERR_NULL;
+    std::lock_guard<std::mutex> g(m->mu);
+    const uint32_t G = (uint32_t)m->shard.size();
+    zip_ctx *lead = m->shard[0];
+    const uint32_t R = lead->p.num_rows, C = lead->p.row_len;
+    const bool single = R == 1;
+    HostField hf;
+    int32_t rc;
+    if ((rc = make_field(lead, field, &hf))) return mfail(m, rc, "field", lead);
+    if (!single && (!coeffs || !q0_mont)) return mfail(m, ZIP_ERR_NULL, "coeffs / q0_mont is NULL");
+    if ((rc = check_cols(lead, cols, n_cols))) return mfail(m, rc, "cols", lead);
+    const uint32_t fl = hf.fl, ml = lead->p.m_limbs;
+    const size_t u_bytes = single ? 0 : (size_t)C * ml * 8, row_bytes = (size_t)C * fl * 8;
+    const size_t rec = 8 + 32 * (size_t)lead->depth, per_col = (size_t)R * (32 + rec);
+    static const uint32_t none = 0;
+    std::vector<zip_commitment *> com(G, nullptr);
+    std::vector<std::unique_ptr<Scratch>> small;
+    std::vector<std::unique_ptr<CombineScratch>> cscr;
+    std::vector<const uint32_t *> cols_dv(G, nullptr);
+    // every exit path: drain the shards, then free the commitments (the scratch objects go after that)
+    auto finish = [&](int32_t code) {
+        for (uint32_t s = 0; s < G; s++) {
+            (void)hipSetDevice(m->shard[s]->device);
+            (void)zip_ctx_synchronize(m->shard[s]);
+            if (com[s]) zip_commitment_free(com[s]);
+        }
+        return code;
+    };
+    // ---- 1. every shard: witness slice, hinted commit (asynchronous), row combinations, openings of its rows
+    for (uint32_t s = 0; s < G; s++) {
+        zip_ctx *ctx = m->shard[s];
+        if (hipSetDevice(ctx->device) != hipSuccess) return finish(mfail(m, ZIP_ERR_HIP, "hipSetDevice failed"));
+        const uint32_t rows = ctx->rows_local, r0 = ctx->p.row_begin;
+        const size_t n = (size_t)rows * C;
+        const int64_t *ev = m->witness[s];
+        zip_mem_kind kind = ZIP_MEM_DEVICE;
+        if (evals) {  // host witness: each shard uploads its own rows (the commitment keeps the device copy)
+            ev = evals + (size_t)r0 * C;
+            kind = ZIP_MEM_HOST;
+        } else if (!ev) {
+            return finish(mfail(m, ZIP_ERR_NULL, "evals is NULL and zip_mctx_set_witness was not called"));
+        }
+        if ((rc = commit_impl(ctx, ev, n, kind, 1, cols ? cols : &none, n_cols, nullptr, &com[s])))
+            return finish(mfail(m, rc, "commit", ctx));
+        const int64_t *ev_d = com[s]->evals ? com[s]->evals : com[s]->evals_ref;
+        const size_t need_slice = (size_t)n_cols * column_bytes(ctx);
+        if (m->slice_bytes[s] < need_slice) {
+            pool_release(ctx, m->slice[s]);
+            m->slice[s] = nullptr;
+            m->slice_bytes[s] = 0;
+            if ((rc = pool_alloc(ctx, need_slice ? need_slice : 16, (void **)&m->slice[s]))) return finish(mfail(m, rc, "openings", ctx));
+            m->slice_bytes[s] = need_slice;
+        }
+        if (!m->upart[s] && (rc = pool_alloc(ctx, (size_t)C * 8 * 8, (void **)&m->upart[s]))) return finish(mfail(m, rc, "partials", ctx));
+        if (!m->fpart[s] && (rc = pool_alloc(ctx, (size_t)C * 8 * 8, (void **)&m->fpart[s]))) return finish(mfail(m, rc, "partials", ctx));
+        small.emplace_back(new Scratch(ctx));
+        cscr.emplace_back(new CombineScratch(ctx));
+        SmallInputs si;
+        if (!single) {
+            si.src[0] = coeffs + r0;
+            si.bytes[0] = (size_t)rows * 8;
+        }
+        si.src[1] = single ? hf.r : q0_mont + (size_t)r0 * fl;
+        si.bytes[1] = (size_t)rows * fl * 8;
+        si.src[2] = cols;
+        si.bytes[2] = (size_t)n_cols * 4;
+        unsigned char *sb;
+        if ((rc = stage_small(ctx, si, *small.back(), &sb))) return finish(mfail(m, rc, "inputs", ctx));
+        cols_dv[s] = reinterpret_cast<const uint32_t *>(sb + si.off[2]);
+        CombineOut o{};
+        o.uprime = single ? nullptr : m->upart[s];
+        o.row_limbs = m->fpart[s];
+        // the pass over the witness first (beside the commit's first chunk), the openings, the fold of the partial
+        // sums last -- the order zip_open uses
+        if ((rc = run_combine(ctx, ev_d, reinterpret_cast<const int64_t *>(sb + si.off[0]),
+                              reinterpret_cast<const uint64_t *>(sb + si.off[1]), &hf, !single, true, o, nullptr,
+                              cscr.back().get(), 1)))
+            return finish(mfail(m, rc, "combine", ctx));
+        if ((rc = run_open_columns_pipelined(com[s], cols_dv[s], n_cols, m->slice[s]))) return finish(mfail(m, rc, "openings", ctx));
+        if ((rc = run_combine(ctx, ev_d, reinterpret_cast<const int64_t *>(sb + si.off[0]),
+                              reinterpret_cast<const uint64_t *>(sb + si.off[1]), &hf, !single, true, o, nullptr,
+                              cscr.back().get(), 2)))
+            return finish(mfail(m, rc, "combine", ctx));
+        if (hipEventRecord(m->combined[s], ctx->stream) != hipSuccess) return finish(mfail(m, ZIP_ERR_HIP, "event record failed"));
+    }
+    // ---- 2. lead shard: pull the partial rows together and add them up (exactly)
+    if (hipSetDevice(lead->device) != hipSuccess) return finish(mfail(m, ZIP_ERR_HIP, "hipSetDevice failed"));
+    if (!m->uparts_all && (rc = pool_alloc(lead, (size_t)64 * C * 8 * 8, (void **)&m->uparts_all))) return finish(mfail(m, rc, "partials", lead));
+    if (!m->fparts_all && (rc = pool_alloc(lead, (size_t)64 * C * 8 * 8, (void **)&m->fparts_all))) return finish(mfail(m, rc, "partials", lead));
+    if (m->ends_cap < u_bytes + row_bytes + 64) {
+        pool_release(lead, m->ends);
+        m->ends = nullptr;
+        if ((rc = pool_alloc(lead, u_bytes + row_bytes + 64, (void **)&m->ends))) return finish(mfail(m, rc, "ends", lead));
+        m->ends_cap = u_bytes + row_bytes + 64;
+    }
+    for (uint32_t s = 0; s < G; s++) {
+        zip_ctx *ctx = m->shard[s];
+        hipError_t e = hipStreamWaitEvent(lead->stream, m->combined[s], 0);
+        if (e == hipSuccess && !single)
+            e = hipMemcpyPeerAsync(m->uparts_all + (size_t)s * C * ml, lead->device, m->upart[s], ctx->device, u_bytes, lead->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyPeerAsync(m->fparts_all + (size_t)s * C * fl, lead->device, m->fpart[s], ctx->device, row_bytes, lead->stream);
+        if (e != hipSuccess) return finish(mfail(m, ZIP_ERR_HIP, hipGetErrorString(e)));
+    }
+    {
+        const dim3 grid((C + 255) / 256), block(256);
+        uint64_t *up = single ? nullptr : reinterpret_cast<uint64_t *>(m->ends);
+        const uint64_t *ua = single ? nullptr : m->uparts_all;
+        uint8_t *row_be = m->ends + u_bytes;
+        LaunchTimer t(lead, "sum_partials_kernel");
+        switch (fl) {
+            case 2: hipLaunchKernelGGL(sum_partials_kernel<2>, grid, block, 0, lead->stream, ua, m->fparts_all, G, C, ml, up, (uint64_t *)nullptr, to_dev<2>(hf), row_be); break;
+            case 3: hipLaunchKernelGGL(sum_partials_kernel<3>, grid, block, 0, lead->stream, ua, m->fparts_all, G, C, ml, up, (uint64_t *)nullptr, to_dev<3>(hf), row_be); break;
+            default: hipLaunchKernelGGL(sum_partials_kernel<4>, grid, block, 0, lead->stream, ua, m->fparts_all, G, C, ml, up, (uint64_t *)nullptr, to_dev<4>(hf), row_be); break;
+        }
+        if (hipGetLastError() != hipSuccess) return finish(mfail(m, ZIP_ERR_HIP, "sum_partials launch failed"));
+    }
+    m->last_cols = n_cols;
+    m->last_fl = fl;
+    // ---- 3. results to the host: every shard sends its own rows over its own link
+    for (uint32_t s = 0; s < G; s++) {
+        zip_ctx *ctx = m->shard[s];
+        if (hipSetDevice(ctx->device) != hipSuccess) return finish(mfail(m, ZIP_ERR_HIP, "hipSetDevice failed"));
+        // (a wait of the pipelined gather that gave up is redone here; synchronises the shard's stream)
+        if ((rc = recover_gather_timeout(com[s], cols_dv[s], n_cols, m->slice[s]))) return finish(mfail(m, rc, "openings", ctx));
+        const uint32_t rows = ctx->rows_local, r0 = ctx->p.row_begin;
+        hipError_t e = hipSuccess;
+        if (roots_out) {
+            if ((rc = wait_ready(com[s], ctx->stream))) return finish(mfail(m, rc, "roots", ctx));
+            e = hipMemcpyAsync(roots_out + (size_t)r0 * 32, com[s]->roots, (size_t)rows * 32, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e == hipSuccess && proof_out && n_cols) {
+            const size_t sp = (size_t)rows * (32 + rec);  // pitch of the shard's slice: one column
+            uint8_t *dst = proof_out + u_bytes;
+            e = hipMemcpy2DAsync(dst + (size_t)r0 * 32, per_col, m->slice[s], sp, (size_t)rows * 32, n_cols, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess)
+                e = hipMemcpy2DAsync(dst + (size_t)R * 32 + (size_t)r0 * rec, per_col, m->slice[s] + (size_t)rows * 32, sp,
+                                     (size_t)rows * rec, n_cols, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e != hipSuccess) return finish(mfail(m, ZIP_ERR_HIP, hipGetErrorString(e)));
+    }
+    if (proof_out) {
+        if (hipSetDevice(lead->device) != hipSuccess) return finish(mfail(m, ZIP_ERR_HIP, "hipSetDevice failed"));
+        hipError_t e = hipSuccess;
+        if (u_bytes) e = hipMemcpyAsync(proof_out, m->ends, u_bytes, hipMemcpyDeviceToHost, lead->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(proof_out + u_bytes + (size_t)n_cols * per_col, m->ends + u_bytes, row_bytes, hipMemcpyDeviceToHost, lead->stream);
+        if (e != hipSuccess) return finish(mfail(m, ZIP_ERR_HIP, hipGetErrorString(e)));
+    }
+    rc = finish(ZIP_OK);
+    for (uint32_t s = 0; s < G && !rc; s++)
+        if ((rc = check_timeout(m->shard[s]))) mfail(m, rc, "pipeline", m->shard[s]);
+    return rc;
 }
 
 int32_t zip_verify(zip_ctx *ctx, const uint8_t *roots, const uint8_t *proof, zip_mem_kind proof_kind, size_t proof_len,
