@@ -63,20 +63,29 @@ class OracleBackend:
 
 def main():
     nv = int(sys.argv[1])
+    hip = len(sys.argv) > 2 and sys.argv[2] == "--hip"  # the PRODUCT backend, every rank on GPU 0 (tests/test_gpu_dist.py)
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     zfull = orc.Zip(nv)
     f = orc.make_field(MODULUS, 4)
     evals = orc.splitmix64(0x5A494E43, 1 << nv)
     begin, count = shard_rows(zfull.num_rows, world, rank)
-    sharded = RowShardedZip(nv, zfull.perm1, zfull.perm2, backend=OracleBackend(zfull, begin, count))
+    if hip:
+        from zinc_amd import cabi
+        from zinc_amd.dist import HipBackend
+
+        torch.cuda.set_device(0)
+        backend = HipBackend(nv, zfull.perm1, zfull.perm2, begin, count, 0)
+    else:
+        backend = OracleBackend(zfull, begin, count)
+    sharded = RowShardedZip(nv, zfull.perm1, zfull.perm2, backend=backend)
     assert (sharded.row_begin, sharded.row_count) == (begin, count)
 
     com, roots_all = sharded.commit(sharded.local_slice(evals))
     point = orc.point_to_field(f, [1] * nv)
     rows_o, layers_o, roots_o = zfull.commit(evals)
     proof_o, cols, coeffs = zfull.open(f, evals, rows_o, layers_o, point, orc.new_transcript())
-    assert np.array_equal(roots_all.numpy(), roots_o), "all-gathered roots differ"
+    assert np.array_equal(roots_all.cpu().numpy(), roots_o), "all-gathered roots differ"
 
     lr = zfull.num_rows.bit_length() - 1
     q0 = orc.build_eq_x_r(f, point[nv - lr:])
@@ -84,7 +93,9 @@ def main():
     class _F:
         limbs = 4
 
-    uprime, row, wire = sharded.open(com, sharded.local_slice(evals), coeffs, cols, q0, _F())
+    field = cabi.make_field(MODULUS, 4) if hip else _F()
+    uprime, row, wire = sharded.open(com, sharded.local_slice(evals), coeffs, cols, q0, field)
+    uprime, row, wire = uprime.cpu(), row.cpu(), wire.cpu()
     wires = [torch.empty_like(wire) for _ in range(world)]
     dist.all_gather(wires, wire)
     if rank == 0:
@@ -93,7 +104,7 @@ def main():
         row_be = b"".join(orc.limbs_to_int(r).to_bytes(32, "big") for r in row.numpy().view(np.uint64))
         proof = np.concatenate([uprime.numpy().view(np.uint8).reshape(-1), body, np.frombuffer(row_be, dtype=np.uint8)])
         assert proof.size == proof_o.size and np.array_equal(proof, proof_o), "sharded proof differs from the unsharded one"
-        print("DIST_OK", world, nv, proof.size, flush=True)
+        print("DIST_OK", world, nv, proof.size, "hip" if hip else "oracle", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -26,7 +26,30 @@ def oracle():
     return _oracle
 
 
+def _run_gpu_dist_rehearsal(session):
+    """tests/test_gpu_dist.py: RowShardedZip + HipBackend + real collectives, two ranks over gloo, both on GPU 0.  Run
+    HERE, before this process has touched the GPU (a GPU-initialised process must not fork + exec on the GPU boxes)."""
+    if not any("test_gpu_dist" in item.nodeid for item in session.items):
+        return
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = {"returncode": None, "stdout": "", "stderr": ""}
+    try:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "tests", "_dist_worker.py"), "12", "--hip"]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="2"))
+        out.update(returncode=res.returncode, stdout=res.stdout, stderr=res.stderr)
+    except Exception as e:  # noqa: BLE001
+        out.update(returncode=-1, stderr=repr(e))
+    session.config._zinc_gpu_dist = out
+
+
 def pytest_collection_finish(session):
+    _run_gpu_dist_rehearsal(session)
     """tests/test_gpu_cpp_mirror.py runs a separate C++ program.  It is built and run HERE, before any test has touched
     the GPU: a process that has initialised HIP must not exec another program on the GPU boxes, and a forked child
     that execs counts.  The test itself only looks at the stored result."""

@@ -114,7 +114,13 @@ class RowShardedZip:
             return t.reshape((1,) + tuple(t.shape))
         # concatenated along dim 0 (the layout both RCCL and gloo accept), viewed as [world, ...]
         out = self.backend.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), t.dtype)
-        self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        if t.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            # rehearsal on a box without RCCL peers (several ranks on one GPU): the exchange goes through the host
+            host = self.torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(host, t.contiguous().cpu(), group=self.group)
+            out.copy_(host)
+        else:
+            self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
         return out.reshape((self.world,) + tuple(t.shape))
 
     def commit(self, evals_local):
