@@ -1208,6 +1208,19 @@ template <int FL, int K, int DEG>
 int32_t launch_sumcheck_round(zip_sumcheck *s, const SumcheckRoundArgs<FL> &a, uint32_t blocks, const FieldDev<FL> &fd) {
     zip_ctx *ctx = s->ctx;
     const size_t lds = (size_t)256 * (DEG + 1) * FL * 8;
+    // a big round runs as exactly the workgroups that are resident together (grid-stride loop inside): a grid of
+    // 8 per CU with 3 resident left a third wave of workgroups two thirds full
+    if (blocks > ctx->num_cus) {
+        static std::mutex mu;
+        static std::map<std::pair<const void *, int>, int> occ;
+        const void *kern = reinterpret_cast<const void *>(sumcheck_round_kernel<FL, K, DEG>);
+        std::lock_guard<std::mutex> g(mu);
+        int &per_cu = occ[std::make_pair(kern, ctx->device)];
+        if (per_cu == 0 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sumcheck_round_kernel<FL, K, DEG>, 256, lds) != hipSuccess)
+            per_cu = 0;
+        if (per_cu > 0) blocks = std::min<uint32_t>(blocks, ctx->num_cus * (uint32_t)per_cu);
+    }
     {
         LaunchTimer t(ctx, "sumcheck_round_kernel");
         hipLaunchKernelGGL((sumcheck_round_kernel<FL, K, DEG>), dim3(blocks), dim3(256), lds, ctx->stream, a, fd);
