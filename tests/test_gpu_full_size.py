@@ -83,7 +83,7 @@ def test_commit_open_2pow24(env):
 
     # zip_commit_open, both variants: the same 1.74 GiB, byte for byte (poisoned buffer first)
     d_ref = torch.from_numpy(proof).cuda()
-    for direct in ("0", "1"):
+    for direct in ("0", "1", "2"):
         os.environ["ZIP_HIP_DIRECT"] = direct
         try:
             d_one = torch.full((proof.size,), 0x33, dtype=torch.uint8, device="cuda")
@@ -229,7 +229,7 @@ def test_commit_open_2pow26_full_on_one_gpu(env):
     com2.free()
 
 
-@pytest.mark.parametrize("hinted", [False, True, "one_call", "one_call_direct"])
+@pytest.mark.parametrize("hinted", [False, True, "one_call", "one_call_direct", "one_call_direct_last"])
 def test_commit_open_2pow22_pipelined_gather_byte_diff(env, hinted, monkeypatch):
     """2^22 with the default chunking (two chunks: the gather of the first runs beside the hashing of the second):
     sampled proof blocks byte for byte against oracle-built rows and paths -- plain commit, hinted commit, and
@@ -245,8 +245,8 @@ def test_commit_open_2pow22_pipelined_gather_byte_diff(env, hinted, monkeypatch)
     d_evals = torch.from_numpy(evals).cuda()
     proof = torch.full((ctx.proof_len(1000, 4),), 0x55, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()  # the fill runs on torch's stream, the library on its own
-    monkeypatch.setenv("ZIP_HIP_DIRECT", "1" if hinted == "one_call_direct" else "0")
-    if hinted in ("one_call", "one_call_direct"):
+    monkeypatch.setenv("ZIP_HIP_DIRECT", {"one_call_direct": "1", "one_call_direct_last": "2"}.get(hinted, "0"))
+    if hinted in ("one_call", "one_call_direct", "one_call_direct_last"):
         _, _, com = ctx.commit_open(d_evals, coeffs, cols, q0, zf, out=proof, want_roots=False, keep=True)
     else:
         com, _ = ctx.commit(d_evals, want_roots=False, hint_cols=cols if hinted else None)  # asynchronous

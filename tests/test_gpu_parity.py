@@ -407,7 +407,7 @@ def test_hinted_commit_opens_bit_exact_and_completes_itself(cabi, geometry):
 
 @pytest.mark.parametrize("geometry", [(16, None), (17, None), (18, None), (20, None), (17, (8192, 16, 16384)), (12, None), (9, None)])
 @pytest.mark.parametrize("device_out", [False, True])
-@pytest.mark.parametrize("direct", ["0", "1"])
+@pytest.mark.parametrize("direct", ["0", "1", "2"])
 def test_commit_open_in_one_call_is_byte_identical(cabi, geometry, device_out, direct, monkeypatch):
     """zip_commit_open (the binding for commit_z_mle_and_prove_evaluation, prover.rs:305-328).  ZIP_HIP_DIRECT=1: the
     commit kernel itself writes the opened values and the three lowest siblings of every path into the proof -- at EVERY

@@ -66,7 +66,9 @@ struct CommitArgs {
     uint32_t rows_total;      // num_rows of the polynomial (this launch covers all of them)
     uint32_t n_open;          // number of openings (length of next[]; firstr[] is padded to the same length)
     const uint64_t *open_tab;  // device: vp[cw / 32] | firstr[n_open] | next[n_open]; copied into LDS by every workgroup
-    uint32_t exp_flags;        // TIMING EXPERIMENTS ONLY (ZIP_HIP_EXP_DIRECT): 1 = look up, do not store; 2 = store to opening 0 without looking up
+    uint32_t direct_from_row;  // MODE 2: rows below this one are stored as in MODE 1 (into rows / layers); the direct
+                               // stores then only serve the rows whose gather ends the step (the last chunk)
+    uint32_t exp_flags;        // TIMING EXPERIMENTS ONLY (ZIP_HIP_EXP_DIRECT): 1 = look up, do not store
 #ifdef ZIPK_DEBUG_STAMPS
     unsigned long long *stamps;  // tools/ubench_pipeline.hip: [chunk][workgroup] wall-clock of each arrival
 #endif
@@ -211,6 +213,7 @@ struct StridedLeaves {
     const uint16_t *dlist = nullptr;
     uint32_t cur = 0;
     uint32_t exp_flags = 0;
+    bool direct = false;  // MODE 2, this row (wave-uniform): into the proof; else as MODE 1
     template <class F>
     __device__ __forceinline__ void for_dests(F f) {
         uint32_t e;
@@ -225,7 +228,7 @@ struct StridedLeaves {
         if (MASKED && !(smask & (1u << E0))) return;
         const uint32_t j = base + E0 * T + tid;
         const uint32_t s = (uint32_t)((int32_t)w2[E0] >> 31);
-        if (MODE == kStoreDirect) {  // rows[r * cw + j] as K little-endian limbs into every opening of column j
+        if (MODE == kStoreDirect && direct) {  // rows[r * cw + j] as K little-endian limbs into every opening of column j
             for_dests([&](uint32_t i) {
                 uint4 *o = reinterpret_cast<uint4 *>(pvals + ((size_t)__umul24(i, per_col8) << 3));
                 if (exp_flags & 1u) { if (i == 0x7FFEu) o[0] = make_uint4(s, s, s, s); return; }
@@ -253,7 +256,7 @@ struct StridedLeaves {
         store_row<E0>();
         blake3_leaf_sext96(w0[E0], w1[E0], w2[E0], h);
         if (!MASKED || (smask & (0x100u << E0))) {
-            if (MODE == kStoreDirect)
+            if (MODE == kStoreDirect && direct)
                 store_sibling<0>(h);
             else
                 store_hash(tree + (size_t)(base + E0 * T + tid) * 8, h);
@@ -265,7 +268,7 @@ struct StridedLeaves {
         if (MASKED && LVL <= 2 && !(smask & ((LVL == 1 ? 0x10000u : 0x1000000u) << (E0 >> LVL)))) return;
         const uint32_t e = E0 + (tid & ((1u << LVL) - 1u));
         const uint32_t n = (base + e * T + tid) >> LVL;
-        if (MODE == kStoreDirect && LVL <= 2)
+        if (MODE == kStoreDirect && direct && LVL <= 2)
             store_sibling<LVL>(h);
         else
             store_hash(tree + ((size_t)level_off(cw, LVL) + n) * 8, h);
@@ -638,6 +641,7 @@ __global__ void __launch_bounds__(1024, MODE != kStoreAll ? 4 : 5) raa_commit_ke
                 src.dlist = dlist;
                 src.cur = dcur0;
                 src.exp_flags = a.exp_flags;
+                src.direct = row >= a.direct_from_row;
             }
 #pragma unroll
             for (int e = 0; e < E; e++) {

@@ -73,6 +73,11 @@ struct zip_ctx {
     unsigned char *bounce[2] = {nullptr, nullptr};
     size_t bounce_cap = 0;
     std::vector<unsigned char *> hint_free;  // pinned kHintBytes blocks of dead hinted commitments
+    // make_field memo: the last zip_field seen and what FieldConfig::new made of it (a HostField, kept as bytes here
+    // because that type is defined further down)
+    zip_field field_cache_in{};
+    alignas(8) unsigned char field_cache_out[256] = {};
+    bool field_cache_valid = false;
     std::string last_error;
     // private plumbing context of a zip_sumcheck / zip_ccs: its blocks go to the process-wide recycle bin
     // when it dies and are taken from there first (these handles live for one proof, hipMalloc is ~ms)
@@ -112,7 +117,8 @@ struct zip_commitment {
     // set (bit c = column c was hinted); anything else asked of the handle first re-runs the commit in full
     // (rematerialize) from the witness: `evals` above, or the caller's device array `evals_ref`.
     bool hinted = false;
-    bool direct = false;  // zip_commit_open: values and level-0..2 siblings went into the proof, not into rows / layers
+    bool direct = false;  // zip_commit_open: values and level-0..2 siblings went into the proof, not into rows / layers ...
+    uint32_t direct_from_row = 0;  // ... for the rows from this one on
     std::vector<uint32_t> hint_cols;
     unsigned char *hint_h = nullptr;  // pinned staging of the bitmaps (returns to ctx->hint_free)
     uint32_t *need_d = nullptr;       // device bitmaps (CommitArgs.need)
@@ -567,6 +573,7 @@ struct HostField {
     uint64_t inv = 0;
     uint64_t quirk_mod = 0;
 };
+static_assert(sizeof(HostField) <= 256, "zip_ctx::field_cache_out holds a HostField");
 
 int cmp_limbs(const uint64_t *a, const uint64_t *b, uint32_t n) {
     for (uint32_t i = n; i-- > 0;)
@@ -589,7 +596,25 @@ void dbl_mod(uint64_t *x, const uint64_t *q, uint32_t n) {
 }
 
 // FieldConfig::new (src/field/config.rs:174-214): R, R^2 mod q and -q^-1 mod 2^64.
+int32_t make_field_uncached(zip_ctx *ctx, const zip_field *zf, HostField *f);
+// FieldConfig::new for the field of this call; the last one is remembered per context (R and R^2 are 512 modular
+// doublings of multi-limb integers: ~10 us on the host, in front of every launch of a proof's PCS step)
 int32_t make_field(zip_ctx *ctx, const zip_field *zf, HostField *f) {
+    if (!zf) return fail(ctx, ZIP_ERR_NULL, "field is NULL");
+    if (ctx && ctx->field_cache_valid && ctx->field_cache_in.limbs == zf->limbs &&
+        !memcmp(ctx->field_cache_in.modulus, zf->modulus, 8 * (size_t)zf->limbs)) {
+        memcpy(f, ctx->field_cache_out, sizeof(HostField));
+        return ZIP_OK;
+    }
+    int32_t rc = make_field_uncached(ctx, zf, f);
+    if (!rc && ctx) {
+        ctx->field_cache_in = *zf;
+        memcpy(ctx->field_cache_out, f, sizeof(HostField));
+        ctx->field_cache_valid = true;
+    }
+    return rc;
+}
+int32_t make_field_uncached(zip_ctx *ctx, const zip_field *zf, HostField *f) {
     if (!zf) return fail(ctx, ZIP_ERR_NULL, "field is NULL");
     if (zf->limbs < 2 || zf->limbs > 4)
         return fail(ctx, ZIP_ERR_UNSUPPORTED, "field limbs %u not in {2,3,4}", zf->limbs);
@@ -725,7 +750,7 @@ bool commit_supports_direct(const zip_ctx *ctx, uint32_t n_cols) {
     // HBM traffic by a third, but the commit kernel pays 0.15 ms for the scattered stores (one memory-pipeline pass
     // per store instruction whatever the number of active lanes) and is the critical path: 2.05-2.09 ms per step
     // against 2.00-2.10 for zip_commit_hinted + the whole gather.  Kept for streams that are HBM-bound beside it.
-    { const char *e = getenv("ZIP_HIP_DIRECT"); if (!e || atoi(e) != 1) return false; }
+    { const char *e = getenv("ZIP_HIP_DIRECT"); if (!e || (atoi(e) != 1 && atoi(e) != 2)) return false; }
     if (ctx->rows_local != ctx->p.num_rows || n_cols == 0 || n_cols > kDirectMaxCols) return false;
     if (cw < 512 || cw > 8192 || ctx->depth < 3) return false;
     const CommitGeom g = commit_geom(cw, ctx->p.row_len);
@@ -965,10 +990,13 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
         const CommitGeom cg = commit_geom(ctx->p.codeword_len, ctx->p.row_len);
         size_t used = (size_t)commit_wgs_per_cu(cg) * cg.lds;
         const size_t rec = 8 + 32 * (size_t)(ctx->depth - skip_low);  // bytes of one record in the LDS image
-        if (skip_low) used += direct_lds_bytes(n_cols);  // zip_commit_open: the destination lists in LDS
+        if (c->direct) used += direct_lds_bytes(n_cols);  // zip_commit_open: the destination lists in LDS
         const size_t free_lds = used < 160u * 1024u ? 160u * 1024u - used : 0;
         // (2.5 KB of slack: LDS is handed out in granules -- 24 records = 10.7 KB did NOT get in beside 148.8 KB)
         while (rpb > 8 && rpb * rec + 2560 > free_lds) rpb -= 8;
+        // beside the direct commit kernel (8 KB of lists): two workgroups per CU rather than one with more rows
+        if (c->direct)
+            while (rpb > 8 && 2 * rpb * rec + 2560 > free_lds) rpb -= 8;
     }
     a.rows_per_block = (row_hi - row_lo) < rpb ? (row_hi - row_lo) : rpb;
     static const int knob_prio = getenv("ZIP_HIP_GATHER_PRIO") ? atoi(getenv("ZIP_HIP_GATHER_PRIO")) : 1;
@@ -993,6 +1021,10 @@ int32_t run_open_columns_pipelined(zip_commitment *c, const uint32_t *cols_dv, u
     if (!c->chunk_done) {
         int32_t rc = wait_ready(c, ctx->stream);
         if (rc) return rc;
+        if (skip_low && c->direct_from_row) {
+            if ((rc = run_open_columns(c, cols_dv, n_cols, out_d, 0, c->direct_from_row, 0))) return rc;
+            return run_open_columns(c, cols_dv, n_cols, out_d, c->direct_from_row, ctx->rows_local, skip_low);
+        }
         return run_open_columns(c, cols_dv, n_cols, out_d, 0, ctx->rows_local, skip_low);
     }
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, c->zeroed, 0));
@@ -1006,7 +1038,8 @@ int32_t run_open_columns_pipelined(zip_commitment *c, const uint32_t *cols_dv, u
                                force_timeout ? 100000ull : 25000000ull /* 0.25 s at 100 MHz */);
             HIP_TRY(ctx, hipGetLastError());
         }
-        int32_t rc = run_open_columns(c, cols_dv, n_cols, out_d, c->bounds[k], c->bounds[k + 1], skip_low);
+        int32_t rc = run_open_columns(c, cols_dv, n_cols, out_d, c->bounds[k], c->bounds[k + 1],
+                                      c->bounds[k] >= c->direct_from_row ? skip_low : 0u);
         if (rc) return rc;
     }
     return ZIP_OK;
@@ -1028,7 +1061,12 @@ int32_t recover_gather_timeout(zip_commitment *c, const uint32_t *cols_dv, uint3
     *ctx->timeout_flag_h = 0;
     int32_t rc = wait_ready(c, ctx->stream);
     if (rc) return rc;
-    if ((rc = run_open_columns(c, cols_dv, n_cols, out_d, 0, ctx->rows_local, skip_low))) return rc;
+    if (skip_low && c->direct_from_row) {
+        if ((rc = run_open_columns(c, cols_dv, n_cols, out_d, 0, c->direct_from_row, 0))) return rc;
+        if ((rc = run_open_columns(c, cols_dv, n_cols, out_d, c->direct_from_row, ctx->rows_local, skip_low))) return rc;
+    } else if ((rc = run_open_columns(c, cols_dv, n_cols, out_d, 0, ctx->rows_local, skip_low))) {
+        return rc;
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ZIP_OK;
 }
@@ -1777,6 +1815,9 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
                 a.rec_bytes = rec;
                 a.rows_total = R;
                 a.n_open = n_hint;
+                // ZIP_HIP_DIRECT=2: only the rows of the LAST chunk -- the ones whose gather ends the step
+                if (atoi(getenv("ZIP_HIP_DIRECT")) == 2 && nch > 1) a.direct_from_row = c->bounds[nch - 1];
+                c->direct_from_row = a.direct_from_row;
                 static const uint32_t exp_direct = getenv("ZIP_HIP_EXP_DIRECT") ? (uint32_t)atoi(getenv("ZIP_HIP_EXP_DIRECT")) : 0u;
                 a.exp_flags = exp_direct;
                 a.open_tab = reinterpret_cast<const uint64_t *>(reinterpret_cast<const unsigned char *>(c->need_d) + kHintTables);
