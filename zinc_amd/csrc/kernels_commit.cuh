@@ -393,31 +393,65 @@ struct ChunkCursor {
     }
 };
 
+// Scratch for finish_chunk: two LDS regions that are dead between the hash phase of a chunk's last row and the scan
+// passes of the next row (the t2 planes).  The nodes of a level stay there for the next level, ping-pong.
+struct UpperScratch {
+    uint32_t *a, *b;       // 8 words per hash
+    uint32_t cap_a, cap_b;  // capacities in hashes
+};
+
 template <bool HASH>
 __device__ __forceinline__ void finish_chunk(const CommitArgs &a, uint32_t first_level, const ChunkCursor &cc,
-                                             uint32_t round, uint32_t tid, uint32_t T) {
+                                             uint32_t round, uint32_t tid, uint32_t T, const UpperScratch &us) {
     const uint32_t cw = a.cw;
     if (HASH) {
         const uint32_t first = cc.first;
         const uint32_t nrows_c = round - first + 1;
         const uint32_t depth = 31u - __builtin_clz(cw);
         __syncthreads();
+        // Levels first_level .. depth of the chunk's rows.  The first level reads its children (written by the
+        // butterflies of this workgroup) back from global memory; from then on a level's nodes are ALSO kept in LDS
+        // for the next one, so that the latency-bound top of the trees is a chain of LDS round trips with LDS-only
+        // barriers, not of L2 round trips with a store drain each (the global stores are fire-and-forget; the
+        // publication below waits for them once).  Falls back to global round trips where a level does not fit.
+        bool in_lds = false;           // the children of `lvl` are in LDS (at us.a or us.b)
+        uint32_t *src_lds = us.a;
+#ifdef ZIPK_EXP_NOFINISH  // timing experiment (tools/ubench_pipeline): what do the upper levels cost?
+        for (uint32_t lvl = first_level; lvl < first_level; lvl++) {
+#else
         for (uint32_t lvl = first_level; lvl <= depth; lvl++) {
+#endif
             const uint32_t wshift = depth - lvl;  // log2(width of this level)
             const uint32_t total = nrows_c << wshift;
+            uint32_t *dst_lds = (in_lds && src_lds == us.a) ? us.b : us.a;
+            const uint32_t dst_cap = dst_lds == us.a ? us.cap_a : us.cap_b;
+            const bool keep = total <= dst_cap && lvl < depth;
             for (uint32_t idx = tid; idx < total; idx += T) {
                 const uint32_t ri = idx >> wshift, i = idx & ((1u << wshift) - 1u);
                 const uint32_t r = blockIdx.x + (first + ri) * gridDim.x;
                 uint32_t *tree = a.layers + (size_t)r * (2u * cw) * 8;
-                const uint32_t *ch = tree + ((size_t)level_off(cw, lvl - 1) + 2u * i) * 8;
                 uint32_t l[8], rr[8], h[8];
-                load_hash(ch, l);
-                load_hash(ch + 8, rr);
+                if (in_lds) {  // children of node idx of this level: nodes 2 idx, 2 idx + 1 of the level below, same row order
+                    load_hash(src_lds + (size_t)(2u * idx) * 8, l);
+                    load_hash(src_lds + (size_t)(2u * idx + 1u) * 8, rr);
+                } else {
+                    const uint32_t *ch = tree + ((size_t)level_off(cw, lvl - 1) + 2u * i) * 8;
+                    load_hash(ch, l);
+                    load_hash(ch + 8, rr);
+                }
                 blake3_node(l, rr, h);
                 store_hash(tree + ((size_t)level_off(cw, lvl) + i) * 8, h);
+                if (keep) store_hash(dst_lds + (size_t)idx * 8, h);
                 if (lvl == depth) store_hash(a.roots + (size_t)r * 8, h);
             }
-            __syncthreads();
+            if (keep) {
+                lds_barrier();
+                in_lds = true;
+                src_lds = dst_lds;
+            } else {
+                __syncthreads();
+                in_lds = false;
+            }
         }
         if (depth == 0 && tid == 0) {  // a one-leaf tree: the root is the leaf hash
             for (uint32_t ri = 0; ri < nrows_c; ri++) {
@@ -501,6 +535,8 @@ __global__ void __launch_bounds__(1024, MODE != kStoreAll ? 4 : 5) raa_commit_ke
     uint64_t *t2lo = reinterpret_cast<uint64_t *>(smem + 512);         // E planes of PS slots
     uint32_t *t2hi = reinterpret_cast<uint32_t *>(t2lo + E * PS);
     int64_t *rowbuf = reinterpret_cast<int64_t *>(t2hi + E * PS);
+    // the t2 planes are dead while a chunk is finished: ping-pong space for the upper tree levels
+    const UpperScratch us{reinterpret_cast<uint32_t *>(t2lo), t2hi, (uint32_t)(E * PS * 8 / 32), (uint32_t)(E * PS * 4 / 32)};
     // MODE 2: the lanes' destination lists (4 per opening: its value and three siblings), built once from the global
     // tables; every lane only ever reads its own stretch, beginning at dcur0
     uint16_t *dlist = reinterpret_cast<uint16_t *>(rowbuf + row_len);
@@ -663,7 +699,7 @@ __global__ void __launch_bounds__(1024, MODE != kStoreAll ? 4 : 5) raa_commit_ke
         // ---- finish a chunk: upper Merkle levels of this workgroup's rows, then publish ------
         const bool last = row + gridDim.x >= a.num_rows;
         if (cc.ends_with(a, round, last)) {
-            finish_chunk<HASH>(a, LOGE + 1, cc, round, tid, T);
+            finish_chunk<HASH>(a, LOGE + 1, cc, round, tid, T, us);
             cc.advance(round);
         }
         ZIPK_PH(ph_c);
@@ -744,6 +780,9 @@ __global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
     // second half of the outputs (phase B) waits in the dead t2 planes
     uint64_t *park_lo = reinterpret_cast<uint64_t *>(smem + 512);         // [8][PS]
     uint32_t *park_hi = reinterpret_cast<uint32_t *>(park_lo + (size_t)8 * PS);  // [8][PS]
+    // ... and, while a chunk is finished, its two halves are ping-pong space for the upper tree levels
+    const UpperScratch us{reinterpret_cast<uint32_t *>(t2lo), reinterpret_cast<uint32_t *>(t2lo + (size_t)8 * PS),
+                          (uint32_t)(8 * PS * 8 / 32), (uint32_t)(8 * PS * 8 / 32)};
 
     // row-invariant store masks of the two output phases under an opening hint
     const uint32_t smask0 = MASKED ? store_mask<8>(a.need, cw, 0u, 16u, (tid0 & ~7u) * 16u + (tid0 & 7u)) : 0xFFFFFFFFu;
@@ -865,7 +904,7 @@ __global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
         }
         const bool last = row + gridDim.x >= a.num_rows;
         if (cc.ends_with(a, round, last)) {
-            finish_chunk<HASH>(a, 4u, cc, round, tid, T);
+            finish_chunk<HASH>(a, 4u, cc, round, tid, T, us);
             cc.advance(round);
         }
     }
