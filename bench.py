@@ -303,14 +303,15 @@ def main():
             else:
                 # commit + open as ONE call, as the prover makes them (commit_z_mle_and_prove_evaluation opens with
                 # a fresh PcsTranscript, src/zinc/prover.rs:305-328: the columns are known before the commit)
-                _, _, com = ctx.commit_open(evals_d, coeffs, cols, q0, zf, out=proof, want_roots=False, keep=True)
+                _, _, com = ctx.commit_open(evals_d, coeffs, cols, q0, zf, out=proof, want_roots=False, keep=world > 1)
             if world > 1:
                 # the one exchange of the commit: every rank's Merkle roots
                 roots_ptr = com.roots_ptr()  # rows=NULL: the 16-byte row entries are not expanded
                 mine = roots_view(torch, roots_ptr, per, dev)
                 dist.all_gather_into_tensor(roots_all, mine if backend == "nccl" else mine.cpu())
                 torch.cuda.current_stream().synchronize()  # the roots buffer returns to the pool below
-        com.free()
+        if com is not None:
+            com.free()
 
     def barrier():
         if world > 1:

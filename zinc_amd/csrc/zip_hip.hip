@@ -2206,6 +2206,7 @@ static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int6
         if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o))) return rc;
     } else if (place == 4) {
         if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o, nullptr, &cscr, 1))) return rc;
+        HIP_TRY(ctx, hipEventRecord(staged, ctx->stream));  // the partial sums exist
     } else if (place == 1 || place == 3) {
         HIP_TRY(ctx, hipEventRecord(staged, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, staged, 0));
@@ -2220,6 +2221,14 @@ static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int6
         return rc;
     if (place == 2) {
         if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o))) return rc;
+    } else if (place == 4 && c->done && c->chunk_done) {
+        // the fold of the partial sums on its own stream, as soon as the commit kernel has ended (only then do its
+        // 126 VGPRs fit on a CU): beside the gather of the last chunk instead of behind it
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, staged, 0));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, c->done, 0));
+        if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o, ctx->s_aux, &cscr, 2))) return rc;
+        HIP_TRY(ctx, hipEventRecord(combined, ctx->s_aux));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, combined, 0));
     } else if (place == 4) {
         if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o, nullptr, &cscr, 2))) return rc;
     } else if (place == 1 || place == 3) {
