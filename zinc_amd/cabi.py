@@ -527,18 +527,19 @@ class Commitment:
         except Exception:
             pass
 
-    def device_ptrs(self, rows=True):
+    def device_ptrs(self, rows=True, layers=True):
         """(rows, layers, roots) device pointers.  Asking for `rows` expands the handle's 16-byte entries into the
-        Int<4> array once (a full-size copy on the device); callers that only need layers / roots pass rows=False
-        and get None for the first element."""
+        Int<4> array once (a full-size copy on the device); asking for rows or layers of a HINTED handle first re-runs
+        the commit in full.  Callers that only need the roots pass rows=False, layers=False (None for those)."""
         r, l, t = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        self.ctx._check(lib().zip_commitment_device_ptrs(self._h, C.byref(r) if rows else None, C.byref(l), C.byref(t)),
+        self.ctx._check(lib().zip_commitment_device_ptrs(self._h, C.byref(r) if rows else None,
+                                                         C.byref(l) if layers else None, C.byref(t)),
                         "zip_commitment_device_ptrs")
-        return (r.value if rows else None), l.value, t.value
+        return (r.value if rows else None), (l.value if layers else None), t.value
 
     def roots_ptr(self):
-        """Device pointer of the row_count x 32-byte Merkle roots (never materialises the rows)."""
-        return self.device_ptrs(rows=False)[2]
+        """Device pointer of the row_count x 32-byte Merkle roots (never materialises or completes anything)."""
+        return self.device_ptrs(rows=False, layers=False)[2]
 
     def download(self, rows=True, layers=True, roots=True):
         c = self.ctx
