@@ -2500,21 +2500,40 @@ int32_t zip_mctx_commit_open(zip_mctx *m, const int64_t *evals, const int64_t *c
         }
         return code;
     };
-    // ---- 1. every shard: witness slice, hinted commit (asynchronous), row combinations, openings of its rows
+    // ---- 0. a host witness goes up first, every shard's rows over its own link at the same time (one host thread
+    //         per shard: the bounce-buffer copy blocks its caller).  A host-side zip_commit would wait for its whole
+    //         commit kernel before returning -- one shard after the other.
+    if (evals) {
+        std::vector<int32_t> up(G, ZIP_OK);
+        std::vector<std::thread> th;
+        for (uint32_t s = 0; s < G; s++) {
+            zip_ctx *ctx = m->shard[s];
+            const size_t n = (size_t)ctx->rows_local * C;
+            if (!m->witness[s]) {
+                if (hipSetDevice(ctx->device) != hipSuccess || pool_alloc(ctx, n * 8, (void **)&m->witness[s])) {
+                    up[s] = ZIP_ERR_ALLOC;
+                    continue;
+                }
+            }
+            th.emplace_back([=, &up]() {
+                if (hipSetDevice(ctx->device) != hipSuccess) { up[s] = ZIP_ERR_HIP; return; }
+                up[s] = copy_h2d_bounced(ctx, m->witness[s], evals + (size_t)ctx->p.row_begin * C, n * 8, ctx->stream);
+                if (!up[s] && hipStreamSynchronize(ctx->stream) != hipSuccess) up[s] = ZIP_ERR_HIP;
+            });
+        }
+        for (auto &t : th) t.join();
+        for (uint32_t s = 0; s < G; s++)
+            if (up[s]) return finish(mfail(m, up[s], "witness upload", m->shard[s]));
+    }
+    // ---- 1. every shard: hinted commit of its rows (asynchronous), row combinations, openings of its rows
     for (uint32_t s = 0; s < G; s++) {
         zip_ctx *ctx = m->shard[s];
         if (hipSetDevice(ctx->device) != hipSuccess) return finish(mfail(m, ZIP_ERR_HIP, "hipSetDevice failed"));
         const uint32_t rows = ctx->rows_local, r0 = ctx->p.row_begin;
         const size_t n = (size_t)rows * C;
         const int64_t *ev = m->witness[s];
-        zip_mem_kind kind = ZIP_MEM_DEVICE;
-        if (evals) {  // host witness: each shard uploads its own rows (the commitment keeps the device copy)
-            ev = evals + (size_t)r0 * C;
-            kind = ZIP_MEM_HOST;
-        } else if (!ev) {
-            return finish(mfail(m, ZIP_ERR_NULL, "evals is NULL and zip_mctx_set_witness was not called"));
-        }
-        if ((rc = commit_impl(ctx, ev, n, kind, 1, cols ? cols : &none, n_cols, nullptr, &com[s])))
+        if (!ev) return finish(mfail(m, ZIP_ERR_NULL, "evals is NULL and zip_mctx_set_witness was not called"));
+        if ((rc = commit_impl(ctx, ev, n, ZIP_MEM_DEVICE, 1, cols ? cols : &none, n_cols, nullptr, &com[s])))
             return finish(mfail(m, rc, "commit", ctx));
         const int64_t *ev_d = com[s]->evals ? com[s]->evals : com[s]->evals_ref;
         const size_t need_slice = (size_t)n_cols * column_bytes(ctx);
