@@ -465,8 +465,10 @@ __device__ __forceinline__ void finish_chunk(const CommitArgs &a, uint32_t first
     if (a.chunk_done) {
         __syncthreads();  // every wave's stores are issued and waited for (vmcnt(0) + barrier)
         if (tid == 0) {
+#ifndef ZIPK_EXP_NOFENCE  // timing experiment only (the gather may then read stale lines)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back has landed before the count moves
+#endif
             __hip_atomic_fetch_add(&a.chunk_done[cc.index], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef ZIPK_DEBUG_STAMPS
             a.stamps[cc.index * gridDim.x + blockIdx.x] = wall_clock64();

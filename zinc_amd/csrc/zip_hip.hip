@@ -184,6 +184,40 @@ int32_t fail(zip_ctx *ctx, int32_t code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                    \
     } while (0)
 
+// Host waits.  A blocked hipStreamSynchronize is woken by an interrupt 20-40 us after the stream has drained -- 1.5 %
+// of a 2 ms commit + open, half of a late sumcheck round.  So: poll the completion signal (hipStreamQuery /
+// hipEventQuery read it from memory) for up to ZIP_HIP_SPIN_US microseconds (default 4000; 0 = never), then block.
+static long spin_budget_us() {
+    static const long us = getenv("ZIP_HIP_SPIN_US") ? atol(getenv("ZIP_HIP_SPIN_US")) : 4000;
+    return us;
+}
+template <class Query>
+static inline bool spin_until_done(Query query, hipError_t *result) {
+    const long budget = spin_budget_us();
+    if (budget <= 0) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 0;; it++) {
+        const hipError_t e = query();
+        // (hipErrorNotReady may be left behind as the thread's "last error": the launch checks must not find it)
+        if (e != hipErrorNotReady) { if (it) (void)hipGetLastError(); *result = e; return true; }
+        if ((it & 15u) == 15u &&
+            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > budget) {
+            (void)hipGetLastError();
+            return false;
+        }
+    }
+}
+static hipError_t stream_wait(hipStream_t s) {
+    hipError_t e = hipSuccess;
+    if (spin_until_done([s] { return hipStreamQuery(s); }, &e)) return e;
+    return hipStreamSynchronize(s);
+}
+static hipError_t event_wait(hipEvent_t ev) {
+    hipError_t e = hipSuccess;
+    if (spin_until_done([ev] { return hipEventQuery(ev); }, &e)) return e;
+    return hipEventSynchronize(ev);
+}
+
 // Device blocks of dead short-lived contexts (ctx->recycle), per device, exact-size lists.  A block enters
 // only after its context synchronised every stream it had, so the next owner may use it at once.
 struct RecycleBin {
@@ -494,12 +528,12 @@ bool host_range_is_pinned(const void *p, size_t bytes) {
 int32_t copy_d2h_bounced(zip_ctx *ctx, void *dst_h, const void *src_d, size_t bytes, hipStream_t after) {
     if (bytes >= kBounceThreshold && host_range_is_pinned(dst_h, bytes)) {
         HIP_TRY(ctx, hipMemcpyAsync(dst_h, src_d, bytes, hipMemcpyDeviceToHost, after));
-        HIP_TRY(ctx, hipStreamSynchronize(after));
+        HIP_TRY(ctx, stream_wait(after));
         return ZIP_OK;
     }
     if (bytes < kBounceThreshold) {
         HIP_TRY(ctx, hipMemcpyAsync(dst_h, src_d, bytes, hipMemcpyDeviceToHost, after));
-        HIP_TRY(ctx, hipStreamSynchronize(after));
+        HIP_TRY(ctx, stream_wait(after));
         return ZIP_OK;
     }
     int32_t rc = ensure_bounce(ctx, kBounceBytes);
@@ -517,11 +551,11 @@ int32_t copy_d2h_bounced(zip_ctx *ctx, void *dst_h, const void *src_d, size_t by
     for (size_t i = 0; i < n && rc == ZIP_OK; i++) {
         if (i + 1 < n) rc = issue(i + 1);  // bounce[(i+1)&1] was drained in iteration i-1
         if (rc) break;
-        if (hipEventSynchronize(ev[i & 1]) != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "device-to-host copy failed"); break; }
+        if (event_wait(ev[i & 1]) != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "device-to-host copy failed"); break; }
         const size_t off = i * chunk, len = std::min(chunk, bytes - off);
         parallel_memcpy(static_cast<char *>(dst_h) + off, ctx->bounce[i & 1], len);
     }
-    (void)hipStreamSynchronize(after);
+    (void)stream_wait(after);
     ctx->dep_event_pool.push_back(ev[0]);
     ctx->dep_event_pool.push_back(ev[1]);
     return rc;
@@ -532,7 +566,7 @@ int32_t copy_d2h_bounced(zip_ctx *ctx, void *dst_h, const void *src_d, size_t by
 int32_t copy_h2d_bounced(zip_ctx *ctx, void *dst_d, const void *src_h, size_t bytes, hipStream_t st) {
     if (bytes >= ctx->h2d_bounce_threshold && host_range_is_pinned(src_h, bytes)) {
         HIP_TRY(ctx, hipMemcpyAsync(dst_d, src_h, bytes, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));  // same contract as below: the caller's buffer is free on return
+        HIP_TRY(ctx, stream_wait(st));  // same contract as below: the caller's buffer is free on return
         return ZIP_OK;
     }
     if (bytes < ctx->h2d_bounce_threshold) {
@@ -546,15 +580,15 @@ int32_t copy_h2d_bounced(zip_ctx *ctx, void *dst_d, const void *src_h, size_t by
     hipEvent_t ev[2] = {take_dep_event(ctx), take_dep_event(ctx)};
     for (size_t i = 0; i < n; i++) {
         const size_t off = i * chunk, len = std::min(chunk, bytes - off);
-        if (i >= 2 && hipEventSynchronize(ev[i & 1]) != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "host-to-device copy failed"); break; }
+        if (i >= 2 && event_wait(ev[i & 1]) != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "host-to-device copy failed"); break; }
         parallel_memcpy(ctx->bounce[i & 1], static_cast<const char *>(src_h) + off, len);
         hipError_t e = hipMemcpyAsync(static_cast<char *>(dst_d) + off, ctx->bounce[i & 1], len, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipEventRecord(ev[i & 1], st);
         if (e != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "host-to-device copy failed: %s", hipGetErrorString(e)); break; }
     }
     // the bounce buffers are reused by the next call: wait for the tail
-    (void)hipEventSynchronize(ev[0]);
-    (void)hipEventSynchronize(ev[1]);
+    (void)event_wait(ev[0]);
+    (void)event_wait(ev[1]);
     ctx->dep_event_pool.push_back(ev[0]);
     ctx->dep_event_pool.push_back(ev[1]);
     return rc;
@@ -857,7 +891,7 @@ struct CombineScratch {
     Scratch pint, pa, pb;
     explicit CombineScratch(zip_ctx *c) : ctx(c), pint(c), pa(c), pb(c) {}
     ~CombineScratch() {
-        if (drain) (void)hipStreamSynchronize(drain);
+        if (drain) (void)stream_wait(drain);
     }
 };
 
@@ -1056,7 +1090,7 @@ size_t column_bytes(const zip_ctx *ctx) {
 int32_t recover_gather_timeout(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d,
                                uint32_t skip_low = 0) {
     zip_ctx *ctx = c->ctx;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx->stream));
     if (!(ctx->timeout_flag_h && *ctx->timeout_flag_h)) return ZIP_OK;
     *ctx->timeout_flag_h = 0;
     int32_t rc = wait_ready(c, ctx->stream);
@@ -1067,7 +1101,7 @@ int32_t recover_gather_timeout(zip_commitment *c, const uint32_t *cols_dv, uint3
     } else if ((rc = run_open_columns(c, cols_dv, n_cols, out_d, 0, ctx->rows_local, skip_low))) {
         return rc;
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx->stream));
     return ZIP_OK;
 }
 
@@ -1229,7 +1263,7 @@ int32_t run_verify_fl(zip_ctx *ctx, const VerifyIn &in, const HostField &hf, std
     }
     std::vector<unsigned char> host(misc_bytes);
     HIP_TRY(ctx, hipMemcpyAsync(host.data(), misc.ptr, misc_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx->stream));
     memcpy(cnt, host.data(), sizeof(VerifyCounters));
     const uint32_t *w = reinterpret_cast<const uint32_t *>(host.data() + sizeof(VerifyCounters));
     flags.assign(w, w + n_cols);
@@ -1594,10 +1628,10 @@ int32_t zip_ctx_create(const zip_params *p, zip_ctx **out) {
 void zip_ctx_destroy(zip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->s_commit) (void)hipStreamSynchronize(ctx->s_commit);
-    if (ctx->s_upper) (void)hipStreamSynchronize(ctx->s_upper);
-    if (ctx->s_aux) (void)hipStreamSynchronize(ctx->s_aux);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->s_commit) (void)stream_wait(ctx->s_commit);
+    if (ctx->s_upper) (void)stream_wait(ctx->s_upper);
+    if (ctx->s_aux) (void)stream_wait(ctx->s_aux);
+    if (ctx->stream) (void)stream_wait(ctx->stream);
     if (ctx->recycle) {
         for (auto &kv : ctx->free_blocks) recycle_give(ctx->device, kv.first, kv.second);
         for (auto &kv : ctx->live_blocks) recycle_give(ctx->device, kv.second, kv.first);
@@ -1641,10 +1675,10 @@ const char *zip_ctx_last_error(const zip_ctx *ctx) { return ctx ? ctx->last_erro
 int32_t zip_ctx_synchronize(zip_ctx *ctx) {
     if (!ctx) return ZIP_ERR_NULL;
     std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
-    if (ctx->s_commit) HIP_TRY(ctx, hipStreamSynchronize(ctx->s_commit));
-    if (ctx->s_upper) HIP_TRY(ctx, hipStreamSynchronize(ctx->s_upper));
-    if (ctx->s_aux) HIP_TRY(ctx, hipStreamSynchronize(ctx->s_aux));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->s_commit) HIP_TRY(ctx, stream_wait(ctx->s_commit));
+    if (ctx->s_upper) HIP_TRY(ctx, stream_wait(ctx->s_upper));
+    if (ctx->s_aux) HIP_TRY(ctx, stream_wait(ctx->s_aux));
+    HIP_TRY(ctx, stream_wait(ctx->stream));
     return check_timeout(ctx);
 }
 
@@ -1848,7 +1882,7 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
             if ((rc = deliver(ctx, roots_out, ZIP_MEM_HOST, c->roots, c->roots_bytes))) break;
         }
         if (evals_kind == ZIP_MEM_HOST) {
-            hipError_t e = hipStreamSynchronize(ctx->s_commit);  // the caller's buffer is free to go
+            hipError_t e = stream_wait(ctx->s_commit);  // the caller's buffer is free to go
             if (e != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "commit failed: %s", hipGetErrorString(e)); break; }
         }
     } while (0);
@@ -1889,11 +1923,11 @@ static int32_t rematerialize(zip_commitment *c) {
     a.chunk_done = nullptr;  // the chunks of the first run stay published
     a.evals = c->evals ? c->evals : c->evals_ref;
     if (c->done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_commit, c->done, 0));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // nobody still gathers from the buffers
+    HIP_TRY(ctx, stream_wait(ctx->stream));  // nobody still gathers from the buffers
     int32_t rc = dispatch_commit<true>(ctx, a, c->grid, ctx->s_commit);
     if (rc) return rc;
     if (c->done) HIP_TRY(ctx, hipEventRecord(c->done, ctx->s_commit));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_commit));
+    HIP_TRY(ctx, stream_wait(ctx->s_commit));
     c->hinted = false;
     c->direct = false;
     return ZIP_OK;
@@ -1915,12 +1949,12 @@ void zip_commitment_free(zip_commitment *c) {
     std::lock_guard<std::recursive_mutex> api_lock(c->ctx->api_mu);
     // nothing may still be reading or writing the buffers when they return to the pool
     if (c->done) {
-        (void)hipEventSynchronize(c->done);
+        (void)event_wait(c->done);
         c->ctx->dep_event_pool.push_back(c->done);
     }
     if (c->zeroed) c->ctx->dep_event_pool.push_back(c->zeroed);
     for (hipEvent_t e : c->aux) c->ctx->dep_event_pool.push_back(e);
-    if (c->ctx->stream) (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->ctx->stream) (void)stream_wait(c->ctx->stream);
     pool_release(c->ctx, c->chunk_done);
     pool_release(c->ctx, c->need_d);
     if (c->hint_h) c->ctx->hint_free.push_back(c->hint_h);
@@ -1963,9 +1997,9 @@ static int32_t materialize_rows(zip_commitment *c) {
     hipLaunchKernelGGL(expand_rows_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(c->rows),
                        static_cast<uint4 *>(full), n);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = stream_wait(ctx->stream);
     if (e != hipSuccess) {
-        (void)hipStreamSynchronize(ctx->stream);  // nothing may still write `full` when it returns to the pool
+        (void)stream_wait(ctx->stream);  // nothing may still write `full` when it returns to the pool
         pool_release(ctx, full);
         return fail(ctx, ZIP_ERR_HIP, "expanding the row entries failed: %s", hipGetErrorString(e));
     }
@@ -2004,7 +2038,7 @@ int32_t zip_commit_download(zip_commitment *c, uint64_t *rows_out, uint8_t *laye
         if (!c->roots) return fail(ctx, ZIP_ERR_INVALID_PARAM, "commitment has no Merkle roots (commit_no_merkle)");
         HIP_TRY(ctx, hipMemcpyAsync(roots_out, c->roots, c->roots_bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx->stream));
     return ZIP_OK;
 }
 
@@ -2038,7 +2072,7 @@ int32_t zip_commitment_upload(zip_ctx *ctx, const uint64_t *rows, const uint8_t 
                                          (size_t)2 * cw * 32, roots, 32, 32, R, hipMemcpyHostToDevice, ctx->stream);
             }
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = stream_wait(ctx->stream);
         if (e != hipSuccess) rc = fail(ctx, ZIP_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
     } while (0);
     if (rc) {
@@ -2076,7 +2110,7 @@ int32_t zip_open_testing(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_
                           false, o)))
         return rc;
     if (out_kind == ZIP_MEM_HOST) return deliver(ctx, uprime_out, ZIP_MEM_HOST, o.uprime, bytes);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // coeffs were read from host memory
+    HIP_TRY(ctx, stream_wait(ctx->stream));  // coeffs were read from host memory
     return ZIP_OK;
 }
 
@@ -2141,7 +2175,7 @@ int32_t zip_open_eval(zip_ctx *ctx, const int64_t *evals, zip_mem_kind evals_kin
                           o)))
         return rc;
     if (out_kind == ZIP_MEM_HOST) return deliver(ctx, row_out, ZIP_MEM_HOST, o.row_limbs, bytes);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx->stream));
     return ZIP_OK;
 }
 
@@ -2443,7 +2477,7 @@ int32_t zip_mctx_set_witness(zip_mctx *m, const int64_t *evals, size_t n_evals) 
         if (!m->witness[s] && (rc = pool_alloc(ctx, n * 8, (void **)&m->witness[s]))) return mfail(m, rc, "witness slice", ctx);
         if ((rc = copy_h2d_bounced(ctx, m->witness[s], evals + (size_t)ctx->p.row_begin * ctx->p.row_len, n * 8, ctx->stream)))
             return mfail(m, rc, "witness upload", ctx);
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return mfail(m, ZIP_ERR_HIP, "witness upload failed");
+        if (stream_wait(ctx->stream) != hipSuccess) return mfail(m, ZIP_ERR_HIP, "witness upload failed");
     }
     return ZIP_OK;
 }
@@ -2518,7 +2552,7 @@ int32_t zip_mctx_commit_open(zip_mctx *m, const int64_t *evals, const int64_t *c
             th.emplace_back([=, &up]() {
                 if (hipSetDevice(ctx->device) != hipSuccess) { up[s] = ZIP_ERR_HIP; return; }
                 up[s] = copy_h2d_bounced(ctx, m->witness[s], evals + (size_t)ctx->p.row_begin * C, n * 8, ctx->stream);
-                if (!up[s] && hipStreamSynchronize(ctx->stream) != hipSuccess) up[s] = ZIP_ERR_HIP;
+                if (!up[s] && stream_wait(ctx->stream) != hipSuccess) up[s] = ZIP_ERR_HIP;
             });
         }
         for (auto &t : th) t.join();
@@ -2866,7 +2900,7 @@ int32_t zip_open_stream(zip_commitment *c, const int64_t *evals, zip_mem_kind ev
     // piece 1: u' (open_z.rs:110-112)
     if (u_bytes) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->bounce[0], ends.ptr, u_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, stream_wait(ctx->stream));
         if (sink(user, ctx->bounce[0], u_bytes)) return fail(ctx, ZIP_ERR_INVALID_PARAM, "the proof sink refused the stream");
     }
     if ((rc = wait_ready(c, ctx->stream))) return rc;
@@ -2895,18 +2929,18 @@ int32_t zip_open_stream(zip_commitment *c, const int64_t *evals, zip_mem_kind ev
         // bounce[g & 1] is free: the sink of group g-2 returned before this iteration began
         if ((status = copy_out(g))) break;
         if (g + 1 < n_groups && (status = launch(g + 1))) break;
-        if (hipEventSynchronize(copied[g & 1]) != hipSuccess) { status = fail(ctx, ZIP_ERR_HIP, "proof copy failed"); break; }
+        if (event_wait(copied[g & 1]) != hipSuccess) { status = fail(ctx, ZIP_ERR_HIP, "proof copy failed"); break; }
         const uint32_t first = (uint32_t)(g * group), cnt = (uint32_t)std::min(group, (size_t)n_cols - first);
         if (sink(user, ctx->bounce[g & 1], (size_t)cnt * colb))
             status = fail(ctx, ZIP_ERR_INVALID_PARAM, "the proof sink refused the stream");
     }
     // drain whatever is still in flight before the scratch buffers return to the pool
-    (void)hipStreamSynchronize(s_copy);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    (void)stream_wait(s_copy);
+    HIP_TRY(ctx, stream_wait(ctx->stream));
     if (status) return status;
     // last piece: the evaluation row (open_z.rs:89-90)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->bounce[0], ends.as<uint8_t>() + u_bytes, row_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx->stream));
     if (sink(user, ctx->bounce[0], row_bytes)) return fail(ctx, ZIP_ERR_INVALID_PARAM, "the proof sink refused the stream");
     return check_timeout(ctx);
 }
@@ -2975,7 +3009,7 @@ int32_t zip_sumcheck_init(int32_t device, const uint64_t *const *mles, zip_mem_k
         if ((rc = pool_alloc(ctx, (size_t)(degree + 1) * elem, (void **)&s->evals_d))) break;
         if ((rc = pool_alloc(ctx, 16, (void **)&s->done_d))) break;
         if (hipMemsetAsync(s->done_d, 0, 16, ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
+        if (stream_wait(ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
         bounce_release(ctx);                  // the tables are up: nothing else of this handle goes through them
         s->evals_pinned = slab_take(device);  // null (all slots busy): the message goes through evals_d and a copy
         if (s->evals_pinned) memset(s->evals_pinned, 0, kSlabSlotBytes);
@@ -3032,12 +3066,12 @@ int32_t zip_sumcheck_round_end(zip_sumcheck *s, uint64_t *evaluations_out) {
             if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
         }
         if (seen) std::atomic_thread_fence(std::memory_order_acquire);
-        else HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        else HIP_TRY(ctx, stream_wait(ctx->stream));
         memcpy(evaluations_out, s->evals_pinned, msg_bytes);
         return ZIP_OK;
     }
     HIP_TRY(ctx, hipMemcpyAsync(evaluations_out, s->evals_d, msg_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx->stream));
     return ZIP_OK;
 }
 
@@ -3052,7 +3086,7 @@ const char *zip_sumcheck_last_error(const zip_sumcheck *s) { return s && s->ctx 
 void zip_sumcheck_free(zip_sumcheck *s) {
     if (!s) return;
     if (s->ctx) {
-        if (s->ctx->stream) (void)hipStreamSynchronize(s->ctx->stream);
+        if (s->ctx->stream) (void)stream_wait(s->ctx->stream);
         slab_give(s->ctx->device, s->evals_pinned);
         if (!s->owned) {  // the caller's tables are not ours to free
             std::lock_guard<std::mutex> g(s->ctx->mu);
@@ -3145,7 +3179,7 @@ int32_t zip_ccs_create(int32_t device, const zip_sparse_matrix *mats, uint32_t t
                     default: hipLaunchKernelGGL(csc_fill_kernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, D.row_ptr, D.col_idx, D.vals, M.n_rows, static_cast<uint32_t *>(cursor), D.row_idx, D.vals_t); break;
                 }
             }
-            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
+            if (hipGetLastError() != hipSuccess || stream_wait(ctx->stream) != hipSuccess) { rc = ZIP_ERR_HIP; break; }
             pool_release(ctx, tmp);
             pool_release(ctx, cursor);
             pool_release(ctx, sums);
@@ -3197,7 +3231,7 @@ int32_t zip_ccs_set_z(zip_ccs *c, const int64_t *z, size_t z_len, zip_mem_kind k
     }
     CCS_DISPATCH_FL(c->fl, ccs_set_z_fl, c, z_d, z_len, hf);
     if (rc) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx->stream));
     c->have_z = true;
     c->have_second = false;
     return ZIP_OK;
@@ -3215,7 +3249,7 @@ int32_t zip_ccs_eq_table(zip_ccs *c, const uint64_t *r, uint32_t slot) {
     HIP_TRY(ctx, hipMemcpyAsync(c->small_d, r, (size_t)c->s * c->fl * 8, hipMemcpyHostToDevice, ctx->stream));
     CCS_DISPATCH_FL(c->fl, ccs_eq_table_fl, c, c->small_d, slot, hf);
     if (rc) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx->stream));
     c->have_eq[slot] = true;
     return ZIP_OK;
 }
@@ -3235,7 +3269,7 @@ int32_t zip_ccs_second_table(zip_ccs *c, const uint64_t *r_x, const uint64_t *ga
     CCS_DISPATCH_FL(c->fl, ccs_second_fl, c, gamma_d, vs_d, hf);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(v_s_out, vs_d, (size_t)c->t * c->fl * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx->stream));
     c->have_second = true;
     return ZIP_OK;
 }
@@ -3255,7 +3289,7 @@ int32_t zip_ccs_eval_matrices(zip_ccs *c, const uint64_t *r_x, const uint64_t *r
     CCS_DISPATCH_FL(c->fl, ccs_eval_matrices_fl, c, out_d, hf);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(v_xy_out, out_d, (size_t)c->t * c->fl * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx->stream));
     return ZIP_OK;
 }
 
@@ -3372,7 +3406,7 @@ int32_t zip_merkle_trees(int32_t device, const uint64_t *leaves, uint32_t leaf_l
         hipError_t e = hipMemcpy2DAsync(layers_out, out_w, layers_d, (size_t)2 * n * 32, out_w, num_trees,
                                         kind == ZIP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
                                         ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = stream_wait(ctx->stream);
         if (e != hipSuccess) rc = ZIP_ERR_HIP;
     } while (0);
     if (kind != ZIP_MEM_HOST) {
@@ -3393,7 +3427,7 @@ int32_t zip_ctx_commit_clock(zip_ctx *ctx, double *mhz_out) {
     if (!ctx || !mhz_out) return ZIP_ERR_NULL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
-    if (ctx->s_commit) HIP_TRY(ctx, hipStreamSynchronize(ctx->s_commit));
+    if (ctx->s_commit) HIP_TRY(ctx, stream_wait(ctx->s_commit));
     const unsigned long long *c = ctx->clock_h;
     *mhz_out = (c && c[3] > c[1] && c[2] > c[0]) ? (double)(c[2] - c[0]) / (double)(c[3] - c[1]) * 100.0 : 0.0;
     return ZIP_OK;
@@ -3403,7 +3437,7 @@ int32_t zip_ctx_profile_read(zip_ctx *ctx, zip_kernel_time *out, uint32_t cap) {
     if (!ctx) return ZIP_ERR_NULL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, stream_wait(ctx->stream));
     for (auto &pe : ctx->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) {
