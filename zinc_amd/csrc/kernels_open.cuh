@@ -369,6 +369,7 @@ struct OpenColsArgs {
     uint32_t compact_rows;
     const uint64_t *layers;  // [num_rows][2*cw][4]
     const uint32_t *cols;    // [n_cols] (device)
+    const uint32_t *order;   // [n_cols] (device) or null: workgroup x -> opening index (see gather_order in zip_hip.hip)
     uint8_t *out;            // wire stream of the openings
     uint32_t num_rows, cw, depth, k_limbs;
     uint32_t row_lo, row_hi;  // rows handled by this launch (one pipeline chunk)
@@ -398,7 +399,7 @@ __global__ void __launch_bounds__(256) open_columns_kernel(OpenColsArgs a) {
     constexpr uint32_t K = 4;               // Int<4> column values (checked by zip_ctx_create)
     constexpr uint32_t RPP = 256 / SLOTS;   // rows per pass of the block
     if (a.prio) __builtin_amdgcn_s_setprio(2);  // memory-bound: do not queue behind older hashing waves
-    const uint32_t ci = blockIdx.x;
+    const uint32_t ci = a.order ? a.order[blockIdx.x] : blockIdx.x;
     const uint32_t col = a.cols[ci];
     const uint32_t d = a.depth, cw2 = 2u * a.cw;
     const uint32_t rec_bytes = 8 + 32 * d;

@@ -99,6 +99,7 @@ struct zip_ctx {
 };
 
 struct zip_commitment {
+    const uint32_t *gather_order = nullptr;  // device, valid during one open: OpenColsArgs.order
     zip_ctx *ctx = nullptr;
     uint64_t *rows = nullptr;   // [rows_local][cw][4], or [rows_local][cw][2] while compact_rows (see materialize_rows)
     bool compact_rows = false;
@@ -996,6 +997,23 @@ int32_t check_cols(zip_ctx *ctx, const uint32_t *cols_h, uint32_t n_cols) {
     return ZIP_OK;
 }
 
+// Which opening a gather workgroup takes.  The openings come in transcript order, i.e. random columns; the tree nodes two
+// openings share (every sibling from the level where their columns fall under one parent's two children) and the
+// neighbours in a 128-byte line are only read from HBM once if the workgroups that want them run at the same time on
+// the SAME XCD (one L2 per XCD).  So: openings sorted by column, and -- workgroup b of a grid row lands on XCD b % 8
+// when the row length is a multiple of 8 -- XCD x takes the x-th eighth of the sorted list, in order.
+void gather_order(const uint32_t *cols, uint32_t n_cols, uint32_t *order) {
+    std::vector<uint32_t> sorted(n_cols);
+    for (uint32_t i = 0; i < n_cols; i++) sorted[i] = i;
+    std::sort(sorted.begin(), sorted.end(), [cols](uint32_t x, uint32_t y) { return cols[x] != cols[y] ? cols[x] < cols[y] : x < y; });
+    if (n_cols % 8 == 0) {
+        const uint32_t per = n_cols / 8;
+        for (uint32_t b = 0; b < n_cols; b++) order[b] = sorted[(b % 8) * per + b / 8];
+    } else {
+        memcpy(order, sorted.data(), (size_t)n_cols * 4);
+    }
+}
+
 // cols_dv: DEVICE pointer (already staged).  Emits the openings of rows [row_lo, row_hi).
 int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d,
                          uint32_t row_lo, uint32_t row_hi, uint32_t skip_low = 0) {
@@ -1006,6 +1024,7 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
     a.compact_rows = c->compact_rows ? 1u : 0u;
     a.layers = reinterpret_cast<const uint64_t *>(c->layers);
     a.cols = cols_dv;
+    a.order = c->gather_order;
     a.out = out_d;
     a.num_rows = ctx->rows_local;
     a.cw = ctx->p.codeword_len;
@@ -2215,8 +2234,21 @@ static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int6
     si.bytes[1] = (size_t)ctx->rows_local * hf.fl * 8;
     si.src[2] = cols;
     si.bytes[2] = (size_t)n_cols * 4;
+    static const bool sorted_gather = !(getenv("ZIP_HIP_GATHER_ORDER") && atoi(getenv("ZIP_HIP_GATHER_ORDER")) == 0);
+    std::vector<uint32_t> order;
+    if (sorted_gather && n_cols > 1) {
+        order.resize(n_cols);
+        gather_order(cols, n_cols, order.data());
+        si.src[3] = order.data();
+        si.bytes[3] = (size_t)n_cols * 4;
+    }
     unsigned char *sb;
     if ((rc = stage_small(ctx, si, small, &sb))) return rc;
+    struct OrderScope {  // the table lives in `small`: no launch may see it after this call
+        zip_commitment *c;
+        ~OrderScope() { c->gather_order = nullptr; }
+    } order_scope{c};
+    c->gather_order = order.empty() ? nullptr : reinterpret_cast<const uint32_t *>(sb + si.off[3]);
     // The two row combinations do not depend on the commitment.  Where to put them (ZIP_HIP_COMBINE):
     //   split (default) the pass over the witness FIRST on the main stream -- the stream would otherwise idle until the
     //                   commit kernel publishes its first chunk, and with s_setprio the pass is not starved by the
