@@ -388,7 +388,10 @@ def main():
         achieved = commit_bytes / (avg_ms * 1e-3) / 1e9
         direct = (not args.no_hint and not args.two_calls and 512 <= cw <= 8192
                   and os.environ.get("ZIP_HIP_DIRECT") == "1")  # commit_supports_direct (zip_hip.hip)
-        mode = "plain" if args.no_hint else "direct" if direct else "hinted"
+        # commit_supports_packed (zip_hip.hip): the 8-entries-per-thread kernel, one call
+        packed = (not args.no_hint and not args.two_calls and not direct and 512 <= cw <= 8192
+                  and os.environ.get("ZIP_HIP_PACKED") != "0")
+        mode = "plain" if args.no_hint else "direct" if direct else "packed" if packed else "hinted"
         moved = commit_moved_bytes(per, row_len, cw, depth, None if args.no_hint else cols, direct)
         pe = pmc_entry(dom, nv, mode) if not rows_mode else None
         traffic = int((2 * pe["fetch_kib"] + pe["write_kib"]) * 1024) if pe else None  # reads x2: profiles/*_fetch_calibration.md
@@ -426,7 +429,8 @@ def main():
                                   "zip_commit_open (one call, as commit_z_mle_and_prove_evaluation: the 1000 columns are "
                                   "known before the commit, prover.rs:316; stores no opening reads are skipped%s)"
                                   % ("; ZIP_HIP_DIRECT=1: values and the three lowest siblings go straight into the proof"
-                                     if direct else ""))},
+                                     if direct else "; what the openings read of the entries and of tree levels 0..2 is "
+                                     "stored packed, in index order" if packed else ""))},
             # the contract's HBM figure for the dominant kernel: SURVEY 8d algorithmic bytes / its launch time / 8 TB/s ...
             "roofline": {"bound": "valu", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -439,6 +443,7 @@ def main():
                                  "materialisation (200 B/coeff); `moved_bytes_per_launch` is what this build stores "
                                  "(16-byte row entries%s); `traffic` = FETCH_SIZE x2 + WRITE_SIZE of the committed PMC pass"
                                  % (per * (2 * cw - 1) / 1e6, "" if args.no_hint else ", only what the hinted openings read"
+                                    + (", levels 0..2 and the entries packed" if packed else "")
                                     + (", the values and three lowest siblings of every opening straight into the proof" if direct else ""))},
             # ... and the roofline that does bind it
             "roofline_valu": valu,

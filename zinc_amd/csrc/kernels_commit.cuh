@@ -38,6 +38,12 @@ struct CommitArgs {
     uint32_t num_rows;          // rows of this ctx (the kernel is persistent: row = blockIdx.x + i * gridDim.x)
     uint32_t rounds_per_chunk;  // a chunk = this many consecutive rounds of gridDim.x rows ...
     uint64_t chunk_ends;        // ... or, when non-zero, bit r set = a chunk ends with round r (unequal chunks, <= 64 rounds)
+    // zip_commit_open, packed openings (MODE kStorePacked): what the hinted openings read of the row entries and of
+    // tree levels 0..2 is stored DENSELY, per row [values 16 B each | level-0 | level-1 | level-2 nodes 32 B each] in
+    // ascending index order, instead of at its sparse natural place (where every 32 bytes read cost a 128-byte line)
+    uint8_t *pk;                // [num_rows][pk_stride]
+    uint32_t pk_stride, pk_off0, pk_off1, pk_off2;  // bytes: row stride, start of the three node sections
+    const uint32_t *pk_tab;     // [waves][16] words: per wave the 32 16-bit section ranks its lanes' stores start at
     uint32_t *chunk_done;       // [chunks] arrival counters, or null
     // Opening hint (zip_commit_hinted): bitmaps of what an open of the hinted columns will ever read, or null =
     // store everything.  Words: [V: cw bits, entry j is opened][N0: cw bits][N1: cw/2][N2: cw/4], N_l bit i = node i
@@ -177,9 +183,13 @@ __device__ __forceinline__ void subtree_hash(Src &src, uint32_t (&h)[8]) {
 // butterfly: at level l a lane exchanges one child hash with lane t ^ 2^(l-1) and ends up
 // with the node of step E0 + (t mod 2^l).  Every lane still hashes E leaves, E/2 ... 1 nodes.
 // MODE 0: every entry and node is stored.  MODE 1 (zip_commit_hinted): stores no opening of the hinted columns reads
-// are predicated off.  MODE 2 (zip_commit_open): as 1, and what the openings read of the entries and of levels
-// 0..2 is written into the proof stream itself (CommitArgs.open_cols) instead of into rows / layers.
-constexpr int kStoreAll = 0, kStoreHinted = 1, kStoreDirect = 2;
+// are predicated off.  MODE 2 (zip_commit_open, opt-in): as 1, and what the openings read of the entries and of levels
+// 0..2 is written into the proof stream itself (CommitArgs.open_cols) instead of into rows / layers.  MODE 3
+// (zip_commit_open): as 1, but those stores go to the packed per-row block (CommitArgs.pk).  A lane's place in a
+// section is the rank of its entry / node among the section's members: the members owned by the lanes of one wave at
+// one store site are consecutive in index order (per parity class for level 1, per tid mod 4 for level 2), so the
+// rank is a per-wave base (pk_tab, row invariant, held in scalar registers) + the number of storing lanes below.
+constexpr int kStoreAll = 0, kStoreHinted = 1, kStoreDirect = 2, kStorePacked = 3;
 
 // 32 bytes to an address that is only 8-byte aligned (a path record starts 8 bytes past a multiple of 32): two
 // global_store_dwordx4 -- the hardware wants dword alignment for them, not 16 bytes -- because what these scattered
@@ -214,6 +224,16 @@ struct StridedLeaves {
     uint32_t cur = 0;
     uint32_t exp_flags = 0;
     bool direct = false;  // MODE 2, this row (wave-uniform): into the proof; else as MODE 1
+    // MODE 3: this row's packed block, the section offsets and the wave's 32 base ranks (two per word)
+    uint8_t *pk_row = nullptr;
+    uint32_t pk_off0 = 0, pk_off1 = 0, pk_off2 = 0;
+    uint32_t ptab[16] = {};
+    template <int K>
+    __device__ __forceinline__ uint32_t pbase() const { return (ptab[K >> 1] >> ((K & 1) * 16)) & 0xFFFFu; }
+    // number of lanes below this one among those of `m` (the lanes executing a predicated store)
+    static __device__ __forceinline__ uint32_t lanes_below(uint64_t m) {
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    }
     template <class F>
     __device__ __forceinline__ void for_dests(F f) {
         uint32_t e;
@@ -235,6 +255,9 @@ struct StridedLeaves {
                 o[0] = make_uint4(w0[E0], w1[E0], w2[E0], s);
                 o[1] = make_uint4(s, s, s, s);
             });
+        } else if (MODE == kStorePacked) {
+            const uint32_t pos = pbase<E0>() + lanes_below(__builtin_amdgcn_ballot_w64(true));
+            *reinterpret_cast<uint4 *>(pk_row + (size_t)pos * 16) = make_uint4(w0[E0], w1[E0], w2[E0], s);
         } else if (compact) {
             *reinterpret_cast<uint4 *>(out_row + (size_t)j * 2) = make_uint4(w0[E0], w1[E0], w2[E0], s);
         } else {
@@ -256,10 +279,14 @@ struct StridedLeaves {
         store_row<E0>();
         blake3_leaf_sext96(w0[E0], w1[E0], w2[E0], h);
         if (!MASKED || (smask & (0x100u << E0))) {
-            if (MODE == kStoreDirect && direct)
+            if (MODE == kStoreDirect && direct) {
                 store_sibling<0>(h);
-            else
+            } else if (MODE == kStorePacked) {
+                const uint32_t pos = pbase<8 + E0>() + lanes_below(__builtin_amdgcn_ballot_w64(true));
+                store_hash(reinterpret_cast<uint32_t *>(pk_row + pk_off0) + (size_t)pos * 8, h);
+            } else {
                 store_hash(tree + (size_t)(base + E0 * T + tid) * 8, h);
+            }
         }
     }
     // node of local level LVL computed by this lane: step E0 + (tid mod 2^LVL)
@@ -268,10 +295,24 @@ struct StridedLeaves {
         if (MASKED && LVL <= 2 && !(smask & ((LVL == 1 ? 0x10000u : 0x1000000u) << (E0 >> LVL)))) return;
         const uint32_t e = E0 + (tid & ((1u << LVL) - 1u));
         const uint32_t n = (base + e * T + tid) >> LVL;
-        if (MODE == kStoreDirect && direct && LVL <= 2)
+        if (MODE == kStoreDirect && direct && LVL <= 2) {
             store_sibling<LVL>(h);
-        else
+        } else if (MODE == kStorePacked && LVL == 1) {  // even lanes own the first half of the group's nodes, odd the second
+            const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+            const bool odd = tid & 1u;
+            const uint32_t pos = (odd ? pbase<16 + (E0 >> 1) * 2 + 1>() : pbase<16 + (E0 >> 1) * 2>()) +
+                                 lanes_below(act & (odd ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull));
+            store_hash(reinterpret_cast<uint32_t *>(pk_row + pk_off1) + (size_t)pos * 8, h);
+        } else if (MODE == kStorePacked && LVL == 2) {  // tid mod 4 = q owns the q-th quarter
+            const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+            const uint32_t q = tid & 3u;
+            constexpr int K0 = 24 + ((E0 >> 2) & 1) * 4;
+            const uint32_t b01 = (q & 1u) ? pbase<K0 + 1>() : pbase<K0>(), b23 = (q & 1u) ? pbase<K0 + 3>() : pbase<K0 + 2>();
+            const uint32_t pos = ((q & 2u) ? b23 : b01) + lanes_below(act & (0x1111111111111111ull << q));
+            store_hash(reinterpret_cast<uint32_t *>(pk_row + pk_off2) + (size_t)pos * 8, h);
+        } else {
             store_hash(tree + ((size_t)level_off(cw, LVL) + n) * 8, h);
+        }
     }
 };
 
@@ -567,6 +608,13 @@ __global__ void __launch_bounds__(1024, MODE != kStoreAll ? 4 : 5) raa_commit_ke
     }
     // ... the lane's store mask under an opening hint ...
     const uint32_t smask = (MASKED && active) ? store_mask<E>(a.need, cw, 0u, a.nact, tid0) : 0xFFFFFFFFu;
+    // ... and (packed openings) the wave's base ranks, wave-uniform
+    uint32_t ptab[16] = {};
+    if (MODE == kStorePacked) {
+        const uint32_t *wt = a.pk_tab + (size_t)__builtin_amdgcn_readfirstlane(tid0 >> 6) * 16;
+#pragma unroll
+        for (int k = 0; k < 16; k++) ptab[k] = __builtin_amdgcn_readfirstlane(wt[k]);
+    }
     // ... and the NEXT witness row, fetched during the scan passes of the current one (rep = 2
     // geometry: row_len == NPF * blockDim; anything else takes the direct path).
     constexpr int NPF = (E >= 2) ? E / 2 : 1;
@@ -680,6 +728,14 @@ __global__ void __launch_bounds__(1024, MODE != kStoreAll ? 4 : 5) raa_commit_ke
                 src.cur = dcur0;
                 src.exp_flags = a.exp_flags;
                 src.direct = row >= a.direct_from_row;
+            }
+            if (MODE == kStorePacked) {
+                src.pk_row = a.pk + (size_t)row * a.pk_stride;
+                src.pk_off0 = a.pk_off0;
+                src.pk_off1 = a.pk_off1;
+                src.pk_off2 = a.pk_off2;
+#pragma unroll
+                for (int k = 0; k < 16; k++) src.ptab[k] = ptab[k];
             }
 #pragma unroll
             for (int e = 0; e < E; e++) {

@@ -375,6 +375,11 @@ struct OpenColsArgs {
     uint32_t row_lo, row_hi;  // rows handled by this launch (one pipeline chunk)
     uint32_t rows_per_block;  // even, or the launch has a single block row
     uint32_t prio;            // s_setprio level of the gather waves (tuning knob)
+    // packed openings (CommitArgs.pk): the column values and the siblings of levels 0..2 are read from the row's packed
+    // block at the ranks of pk_rank[opening] = {value, level 0, level 1, level 2} instead of from rows / layers
+    const uint8_t *pk;
+    uint32_t pk_stride, pk_off0, pk_off1, pk_off2;
+    const uint16_t *pk_rank;  // [n_cols][4] (device)
     uint32_t skip_low;        // zip_commit_open: the column values and the siblings of the levels below this one are
                               // already in the proof (written by the commit kernel, CommitArgs.open_cols): neither
                               // read nor written here.  0: the whole opening.
@@ -420,8 +425,14 @@ __global__ void __launch_bounds__(256) open_columns_kernel(OpenColsArgs a) {
         const uint32_t lvl = h >> 1;
         const uint32_t node = cw2 - (cw2 >> lvl) + ((col >> lvl) ^ 1u);
         const uint64_t *src = a.layers + ((size_t)(r0 + rsub) * cw2 + node) * 4 + (h & 1) * 2;
+        size_t src_step = (size_t)RPP * cw2 * 4;
+        if (a.pk && lvl < 3) {
+            const uint32_t off = lvl == 0 ? a.pk_off0 : lvl == 1 ? a.pk_off1 : a.pk_off2;
+            src = reinterpret_cast<const uint64_t *>(a.pk + (size_t)(r0 + rsub) * a.pk_stride + off +
+                                                     (size_t)a.pk_rank[ci * 4 + 1 + lvl] * 32) + (h & 1) * 2;
+            src_step = (size_t)RPP * (a.pk_stride / 8);
+        }
         unsigned char *dst = img + (size_t)rsub * img_rec + 8 + (size_t)(h - 2 * a.skip_low) * 16;
-        const size_t src_step = (size_t)RPP * cw2 * 4;
         const uint32_t dst_step = RPP * img_rec;
         if (h < 2 * d && lvl >= a.skip_low) {
 #pragma unroll 4
@@ -443,7 +454,8 @@ __global__ void __launch_bounds__(256) open_columns_kernel(OpenColsArgs a) {
             const uint32_t r = r0 + rsub;
             ulonglong2 v;
             if (a.compact_rows) {  // (w0, w1, w2, sign): the upper half of the Int<4> is the sign word four times
-                const uint4 e = *reinterpret_cast<const uint4 *>(a.rows + ((size_t)r * a.cw + col) * 2);
+                const uint4 e = a.pk ? *reinterpret_cast<const uint4 *>(a.pk + (size_t)r * a.pk_stride + (size_t)a.pk_rank[ci * 4] * 16)
+                                     : *reinterpret_cast<const uint4 *>(a.rows + ((size_t)r * a.cw + col) * 2);
                 const uint64_t ss = ((uint64_t)e.w << 32) | e.w;
                 v.x = half ? ss : ((uint64_t)e.y << 32) | e.x;
                 v.y = half ? ss : ((uint64_t)e.w << 32) | e.z;

@@ -120,6 +120,13 @@ struct zip_commitment {
     bool hinted = false;
     bool direct = false;  // zip_commit_open: values and level-0..2 siblings went into the proof, not into rows / layers ...
     uint32_t direct_from_row = 0;  // ... for the rows from this one on
+    // zip_commit_open, packed openings: values and level-0..2 nodes of the hinted columns sit densely in `rows`
+    // (CommitArgs.pk); hint_bm = the four bitmaps V | N0 | N1 | N2 the ranks are taken from
+    bool packed = false;
+    uint32_t pk_stride = 0, pk_off[3] = {};
+    std::vector<uint32_t> hint_bm;
+    std::vector<uint16_t> hint_pref;  // per word of hint_bm: set bits of ITS bitmap before that word
+    const uint16_t *gather_rank = nullptr;  // device, valid during one open: OpenColsArgs.pk_rank
     std::vector<uint32_t> hint_cols;
     unsigned char *hint_h = nullptr;  // pinned staging of the bitmaps (returns to ctx->hint_free)
     uint32_t *need_d = nullptr;       // device bitmaps (CommitArgs.need)
@@ -796,6 +803,72 @@ bool commit_supports_direct(const zip_ctx *ctx, uint32_t n_cols) {
     return g.lds + direct_lds_bytes(n_cols) + 64 <= 160u * 1024u;
 }
 
+// ---- packed openings (CommitArgs.pk) --------------------------------------------------------------------------
+// Number of set bits of a bitmap below index i.
+static uint32_t bits_below(const uint32_t *bm, uint32_t i) {
+    uint32_t n = 0;
+    for (uint32_t w = 0; w < (i >> 5); w++) n += (uint32_t)__builtin_popcount(bm[w]);
+    if (i & 31u) n += (uint32_t)__builtin_popcount(bm[i >> 5] & ((1u << (i & 31u)) - 1u));
+    return n;
+}
+struct PackedLayout {
+    uint32_t stride = 0, off[3] = {};
+};
+// bm = V | N0 (cw bits each) | N1 (cw / 2) | N2 (cw / 4), as commit_impl builds them
+static PackedLayout packed_layout(const uint32_t *bm, uint32_t cw) {
+    const uint32_t wv = (cw + 31) / 32, w1 = (cw / 2 + 31) / 32;
+    const uint32_t *nv = bm, *n0 = nv + wv, *n1 = n0 + wv, *n2 = n1 + w1;
+    PackedLayout L;
+    uint32_t at = (bits_below(nv, cw) * 16u + 127u) & ~127u;
+    L.off[0] = at;
+    at = (at + bits_below(n0, cw) * 32u + 127u) & ~127u;
+    L.off[1] = at;
+    at = (at + bits_below(n1, cw / 2) * 32u + 127u) & ~127u;
+    L.off[2] = at;
+    at = (at + bits_below(n2, cw / 4) * 32u + 127u) & ~127u;
+    L.stride = at;
+    return L;
+}
+// CommitArgs.pk_tab: per wave w of the T = cw / 8 threads, 32 ranks (two per word): V and N0 of step e at
+// e * T + 64 w; N1 of group g, parity p at g * T + p * T / 2 + 32 w; N2 of group g, tid mod 4 = q at
+// g * T + q * T / 4 + 16 w -- the first index the wave's lanes own at that store site (StridedLeaves)
+static void packed_wave_table(const uint32_t *bm, uint32_t cw, uint32_t *tab) {
+    const uint32_t T = cw / 8, waves = T / 64, wv = (cw + 31) / 32, w1 = (cw / 2 + 31) / 32;
+    const uint32_t *nv = bm, *n0 = nv + wv, *n1 = n0 + wv, *n2 = n1 + w1;
+    // prefix counts at multiples of 16 are all this needs
+    auto prefix16 = [](const uint32_t *b, uint32_t bits) {
+        std::vector<uint16_t> p(bits / 16 + 1);
+        uint32_t n = 0;
+        for (uint32_t i = 0; i <= bits / 16; i++) {
+            p[i] = (uint16_t)n;
+            if (i < bits / 16) n += (uint32_t)__builtin_popcount((b[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu);
+        }
+        return p;
+    };
+    const std::vector<uint16_t> pv = prefix16(nv, cw), p0 = prefix16(n0, cw), p1 = prefix16(n1, cw / 2), p2 = prefix16(n2, cw / 4);
+    for (uint32_t w = 0; w < waves; w++) {
+        uint16_t v[32];
+        for (uint32_t e = 0; e < 8; e++) {
+            v[e] = pv[(e * T + 64 * w) / 16];
+            v[8 + e] = p0[(e * T + 64 * w) / 16];
+        }
+        for (uint32_t g = 0; g < 4; g++)
+            for (uint32_t par = 0; par < 2; par++) v[16 + 2 * g + par] = p1[(g * T + par * (T / 2) + 32 * w) / 16];
+        for (uint32_t g = 0; g < 2; g++)
+            for (uint32_t q = 0; q < 4; q++) v[24 + 4 * g + q] = p2[(g * T + q * (T / 4) + 16 * w) / 16];
+        for (uint32_t k = 0; k < 16; k++) tab[w * 16 + k] = (uint32_t)v[2 * k] | ((uint32_t)v[2 * k + 1] << 16);
+    }
+}
+// zip_commit_open stores the low part of the openings packed where the commit kernel has the variant (8 entries per
+// thread, whole waves) and the packed rows fit the buffer of the 16-byte row entries they replace
+static bool commit_supports_packed(const zip_ctx *ctx, const PackedLayout &L) {
+    { const char *e = getenv("ZIP_HIP_PACKED"); if (e && atoi(e) == 0) return false; }  // (read per call: the tests flip it)
+    const uint32_t cw = ctx->p.codeword_len;
+    const CommitGeom g = commit_geom(cw, ctx->p.row_len);
+    if (g.e != 8 || cw < 512 || g.threads != cw / 8 || ctx->depth < 3) return false;
+    return L.stride > 0 && (size_t)L.stride <= (size_t)cw * 16 && (size_t)(cw / 8 / 64) * 64 <= kHintBytes - kHintTables;
+}
+
 template <bool HASH>
 int32_t dispatch_commit(zip_ctx *ctx, CommitArgs a, uint32_t grid, hipStream_t st) {
     const CommitGeom g = commit_geom(a.cw, a.row_len);
@@ -803,11 +876,14 @@ int32_t dispatch_commit(zip_ctx *ctx, CommitArgs a, uint32_t grid, hipStream_t s
     if (HASH && a.need) {  // opening hint: only the two big geometries have a masked variant (commit_supports_hint)
         if (g.e == 8 && a.open_cols) return launch_commit<8, HASH, HASH ? kStoreDirect : kStoreAll>(ctx, a, g.threads, grid, st);
         a.open_cols = nullptr;
+        if (g.e == 8 && a.pk) return launch_commit<8, HASH, HASH ? kStorePacked : kStoreAll>(ctx, a, g.threads, grid, st);
+        a.pk = nullptr;
         if (g.e == 16) return launch_commit16<HASH, HASH>(ctx, a, grid, st);
         if (g.e == 8) return launch_commit<8, HASH, HASH ? kStoreHinted : kStoreAll>(ctx, a, g.threads, grid, st);
         a.need = nullptr;
     }
     a.open_cols = nullptr;
+    a.pk = nullptr;
     switch (g.e) {
         case 16: return launch_commit16<HASH>(ctx, a, grid, st);
         case 8: return launch_commit<8, HASH>(ctx, a, g.threads, grid, st);
@@ -1025,6 +1101,15 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
     a.layers = reinterpret_cast<const uint64_t *>(c->layers);
     a.cols = cols_dv;
     a.order = c->gather_order;
+    if (c->packed) {
+        if (!c->gather_rank) return fail(ctx, ZIP_ERR_INVALID_PARAM, "packed commitment opened without its rank table");
+        a.pk = reinterpret_cast<const uint8_t *>(c->rows);
+        a.pk_stride = c->pk_stride;
+        a.pk_off0 = c->pk_off[0];
+        a.pk_off1 = c->pk_off[1];
+        a.pk_off2 = c->pk_off[2];
+        a.pk_rank = c->gather_rank;
+    }
     a.out = out_d;
     a.num_rows = ctx->rows_local;
     a.cw = ctx->p.codeword_len;
@@ -1838,6 +1923,26 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
             c->hint_cols.assign(nv, nv + wv);
             size_t upload = words * 4;
             const bool direct = open_cols_d && commit_supports_direct(ctx, n_hint);
+            if (open_cols_d && !direct && c->compact_rows && n_hint) {
+                const PackedLayout L = packed_layout(bm, cw);
+                if (commit_supports_packed(ctx, L)) {
+                    packed_wave_table(bm, cw, reinterpret_cast<uint32_t *>(c->hint_h + kHintTables));
+                    upload = kHintTables + (size_t)(cw / 8 / 64) * 64;
+                    c->packed = true;
+                    c->pk_stride = L.stride;
+                    for (int k = 0; k < 3; k++) c->pk_off[k] = L.off[k];
+                    c->hint_bm.assign(bm, bm + words);
+                    c->hint_pref.resize(words);
+                    const size_t starts[5] = {0, wv, 2 * (size_t)wv, 2 * (size_t)wv + w1, words};
+                    for (int b = 0; b < 4; b++) {
+                        uint32_t n = 0;
+                        for (size_t w = starts[b]; w < starts[b + 1]; w++) {
+                            c->hint_pref[w] = (uint16_t)n;
+                            n += (uint32_t)__builtin_popcount(bm[w]);
+                        }
+                    }
+                }
+            }
             if (direct) {
                 // column -> openings lists (CommitArgs.open_tab): vp[cw / 32] | firstr[n] | next[n]
                 uint64_t *vp = reinterpret_cast<uint64_t *>(c->hint_h + kHintTables);
@@ -1861,6 +1966,14 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
             if (e != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "hint upload failed: %s", hipGetErrorString(e)); break; }
             a.need = c->need_d;
             c->hinted = true;
+            if (c->packed) {
+                a.pk = reinterpret_cast<uint8_t *>(c->rows);
+                a.pk_stride = c->pk_stride;
+                a.pk_off0 = c->pk_off[0];
+                a.pk_off1 = c->pk_off[1];
+                a.pk_off2 = c->pk_off[2];
+                a.pk_tab = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(c->need_d) + kHintTables);
+            }
             if (direct) {
                 const uint32_t rec = 8 + 32 * ctx->depth;
                 a.open_cols = open_cols_d;
@@ -1938,6 +2051,7 @@ static int32_t rematerialize(zip_commitment *c) {
     CommitArgs a = c->args;
     a.need = nullptr;
     a.open_cols = nullptr;
+    a.pk = nullptr;
     a.clock = nullptr;
     a.chunk_done = nullptr;  // the chunks of the first run stay published
     a.evals = c->evals ? c->evals : c->evals_ref;
@@ -1949,6 +2063,7 @@ static int32_t rematerialize(zip_commitment *c) {
     HIP_TRY(ctx, stream_wait(ctx->s_commit));
     c->hinted = false;
     c->direct = false;
+    c->packed = false;
     return ZIP_OK;
 }
 
@@ -1956,6 +2071,7 @@ static int32_t rematerialize(zip_commitment *c) {
 static int32_t ensure_columns(zip_commitment *c, const uint32_t *cols, uint32_t n_cols) {
     if (!c->hinted) return ZIP_OK;
     if (c->direct) return rematerialize(c);  // the low levels of the hinted columns only exist in that call's proof
+    if (c->packed) return rematerialize(c);  // ... or in the packed blocks only the one call that made them reads
     for (uint32_t i = 0; i < n_cols; i++) {
         const uint32_t col = cols[i];
         if ((col >> 5) >= c->hint_cols.size() || !((c->hint_cols[col >> 5] >> (col & 31)) & 1u)) return rematerialize(c);
@@ -2242,13 +2358,36 @@ static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int6
         si.src[3] = order.data();
         si.bytes[3] = (size_t)n_cols * 4;
     }
+    std::vector<uint16_t> ranks;
+    if (c->packed) {  // where each opening finds its value and its three lowest siblings in a row's packed block
+        const uint32_t cw = ctx->p.codeword_len, wv = (cw + 31) / 32, w1 = (cw / 2 + 31) / 32;
+        const uint32_t *bmw = c->hint_bm.data();
+        const uint16_t *pref = c->hint_pref.data();
+        const uint32_t start[4] = {0, wv, 2 * wv, 2 * wv + w1};  // first word of V, N0, N1, N2
+        auto rank = [&](int b, uint32_t i) {
+            const uint32_t w = start[b] + (i >> 5);
+            return (uint16_t)(pref[w] + (uint32_t)__builtin_popcount(bmw[w] & ((1u << (i & 31u)) - 1u)));
+        };
+        ranks.resize((size_t)n_cols * 4);
+        for (uint32_t i = 0; i < n_cols; i++) {
+            const uint32_t col = cols[i];
+            if (!((bmw[col >> 5] >> (col & 31u)) & 1u)) return fail(ctx, ZIP_ERR_INVALID_PARAM, "column %u is not in the commit's hint", col);
+            ranks[4 * i] = rank(0, col);
+            ranks[4 * i + 1] = rank(1, col ^ 1u);
+            ranks[4 * i + 2] = rank(2, (col >> 1) ^ 1u);
+            ranks[4 * i + 3] = rank(3, (col >> 2) ^ 1u);
+        }
+        si.src[4] = ranks.data();
+        si.bytes[4] = ranks.size() * 2;
+    }
     unsigned char *sb;
     if ((rc = stage_small(ctx, si, small, &sb))) return rc;
-    struct OrderScope {  // the table lives in `small`: no launch may see it after this call
+    struct OrderScope {  // the tables live in `small`: no launch may see them after this call
         zip_commitment *c;
-        ~OrderScope() { c->gather_order = nullptr; }
+        ~OrderScope() { c->gather_order = nullptr; c->gather_rank = nullptr; }
     } order_scope{c};
     c->gather_order = order.empty() ? nullptr : reinterpret_cast<const uint32_t *>(sb + si.off[3]);
+    c->gather_rank = ranks.empty() ? nullptr : reinterpret_cast<const uint16_t *>(sb + si.off[4]);
     // The two row combinations do not depend on the commitment.  Where to put them (ZIP_HIP_COMBINE):
     //   split (default) the pass over the witness FIRST on the main stream -- the stream would otherwise idle until the
     //                   commit kernel publishes its first chunk, and with s_setprio the pass is not starved by the
