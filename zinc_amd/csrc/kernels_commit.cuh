@@ -822,8 +822,10 @@ __device__ __forceinline__ void transpose8(uint32_t (&x)[8], uint32_t lane) {
     transpose8_stage<2>(x, (lane >> 2) & 1u);
 }
 
-template <uint32_t T, bool HASH, bool MASKED = false>
+template <uint32_t T, bool HASH, int MODE = kStoreAll>
 __global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
+    constexpr bool MASKED = MODE != kStoreAll;
+    static_assert(MODE == kStoreAll || MODE == kStoreHinted || MODE == kStorePacked, "no direct variant");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int E = 16;
     constexpr uint32_t PS = T + 2;  // plane stride of the 16 t2 planes
@@ -845,6 +847,17 @@ __global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
     // row-invariant store masks of the two output phases under an opening hint
     const uint32_t smask0 = MASKED ? store_mask<8>(a.need, cw, 0u, 16u, (tid0 & ~7u) * 16u + (tid0 & 7u)) : 0xFFFFFFFFu;
     const uint32_t smask1 = MASKED ? store_mask<8>(a.need, cw, 0u, 16u, (tid0 & ~7u) * 16u + 8u + (tid0 & 7u)) : 0xFFFFFFFFu;
+    // packed openings: the wave's base ranks of both output phases, wave-uniform (CommitArgs.pk_tab)
+    // (two arrays and a select, not one array indexed by the phase: see transpose8_stage)
+    uint32_t ptab0[16] = {}, ptab1[16] = {};
+    if (MODE == kStorePacked) {
+        const uint32_t *wt = a.pk_tab + (size_t)__builtin_amdgcn_readfirstlane(tid0 >> 6) * 32;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            ptab0[k] = __builtin_amdgcn_readfirstlane(wt[k]);
+            ptab1[k] = __builtin_amdgcn_readfirstlane(wt[16 + k]);
+        }
+    }
 
     uint32_t round = 0;
     ChunkCursor cc;
@@ -938,7 +951,15 @@ __global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
             transpose8(x0, tid);
             transpose8(x1, tid);
             transpose8(x2, tid);
-            StridedLeaves<8, MASKED ? kStoreHinted : kStoreAll> src;
+            StridedLeaves<8, MODE> src;
+            if (MODE == kStorePacked) {
+                src.pk_row = a.pk + (size_t)row * a.pk_stride;
+                src.pk_off0 = a.pk_off0;
+                src.pk_off1 = a.pk_off1;
+                src.pk_off2 = a.pk_off2;
+#pragma unroll
+                for (int k = 0; k < 16; k++) src.ptab[k] = q ? ptab1[k] : ptab0[k];
+            }
             src.out_row = out_row;
             src.compact = a.compact_rows;
             src.tree = HASH ? a.layers + (size_t)row * (2u * cw) * 8 : nullptr;

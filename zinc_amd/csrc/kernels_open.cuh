@@ -519,4 +519,77 @@ __global__ void __launch_bounds__(256) open_columns_kernel(OpenColsArgs a) {
     }
 }
 
+// The same openings without the LDS image (skip_low == 0): every lane moves 16 bytes per row straight from where they
+// are to where the wire format wants them.  The siblings of a record sit at 8 (mod 16) in every other record, so the
+// stores are 16-byte stores to 8-byte-aligned addresses (global_store_dwordx4 only wants dword alignment); the lanes
+// of a row still write one contiguous run.  Roles of the SLOTS lanes reserved per row:
+//   h < 2 depth        half (h & 1) of the level-(h >> 1) sibling
+//   h == 2 depth       the record's first 16 bytes: be64(depth) and, again, the first 8 bytes of the level-0 sibling
+//                      (the same bytes lane 0 writes -- so that this lane, too, is "load 16, store 16")
+//   h == 2 depth + 1,2 the two 16-byte halves of the column value (open_z.rs:130-137)
+// One instruction stream for all of them (the role is a select on the loaded data); no LDS, no barrier, 21 VGPRs:
+// nothing but registers bounds how many of its waves fit beside the commit kernel.  Used where the commit kernel
+// leaves too little LDS for a useful image (cw = 16384); beside the 8-entry commit kernel its waves, which never wait
+// at a barrier, take more issue slots from the hashing waves than they save (EXPERIMENTS.md).
+struct __attribute__((packed, aligned(8))) oc_u128_a8 { uint64_t x, y; };
+
+template <int SLOTS>
+__global__ void __launch_bounds__(256) open_columns_stream_kernel(OpenColsArgs a) {
+    constexpr uint32_t K = 4;               // Int<4> column values (checked by zip_ctx_create)
+    constexpr uint32_t RPP = 256 / SLOTS;   // rows per pass of the block
+    if (a.prio) __builtin_amdgcn_s_setprio(2);
+    const uint32_t ci = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    const uint32_t col = a.cols[ci];
+    const uint32_t d = a.depth, cw2 = 2u * a.cw;
+    const uint32_t rec_bytes = 8 + 32 * d;
+    const size_t col_bytes = (size_t)a.num_rows * (8 * K + rec_bytes);
+    uint8_t *base = a.out + (size_t)ci * col_bytes;
+    const uint32_t r0 = a.row_lo + blockIdx.y * a.rows_per_block;
+    const uint32_t r1 = min(r0 + a.rows_per_block, a.row_hi);
+    const uint32_t nrows = r1 - r0;
+    const uint32_t h = threadIdx.x & (SLOTS - 1), rsub = threadIdx.x / SLOTS;
+    if (h > 2 * d + 2) return;
+    const bool is_hdr = h == 2 * d, is_val = h > 2 * d;
+    const uint32_t half = is_val ? h - 2 * d - 1 : (h & 1u);
+    const uint32_t lvl = (is_hdr || is_val) ? 0u : h >> 1;
+    const uint32_t row = r0 + rsub;
+    // source: a tree node (or its packed copy), or the column's row entry
+    const uint8_t *src;
+    size_t src_step;
+    if (is_val) {
+        if (a.pk) {
+            src = a.pk + (size_t)row * a.pk_stride + (size_t)a.pk_rank[ci * 4] * 16;
+            src_step = (size_t)RPP * a.pk_stride;
+        } else if (a.compact_rows) {
+            src = reinterpret_cast<const uint8_t *>(a.rows + ((size_t)row * a.cw + col) * 2);
+            src_step = (size_t)RPP * a.cw * 16;
+        } else {
+            src = reinterpret_cast<const uint8_t *>(a.rows + ((size_t)row * a.cw + col) * K + half * 2);
+            src_step = (size_t)RPP * a.cw * 8 * K;
+        }
+    } else if (a.pk && lvl < 3) {
+        const uint32_t off = lvl == 0 ? a.pk_off0 : lvl == 1 ? a.pk_off1 : a.pk_off2;
+        src = a.pk + (size_t)row * a.pk_stride + off + (size_t)a.pk_rank[ci * 4 + 1 + lvl] * 32 + (is_hdr ? 0u : half * 16u);
+        src_step = (size_t)RPP * a.pk_stride;
+    } else {
+        const uint32_t node = cw2 - (cw2 >> lvl) + ((col >> lvl) ^ 1u);
+        src = reinterpret_cast<const uint8_t *>(a.layers + ((size_t)row * cw2 + node) * 4) + (is_hdr ? 0u : half * 16u);
+        src_step = (size_t)RPP * cw2 * 32;
+    }
+    uint8_t *dst = is_val ? base + (size_t)row * 8 * K + half * 16
+                          : base + (size_t)a.num_rows * 8 * K + (size_t)row * rec_bytes + (is_hdr ? 0u : 8u + h * 16u);
+    const size_t dst_step = is_val ? (size_t)RPP * 8 * K : (size_t)RPP * rec_bytes;
+    const bool val_hi = is_val && half && a.compact_rows;  // the upper half of a 16-byte row entry's Int<4>: sign words
+    const uint64_t hdr = __builtin_bswap64((uint64_t)d);
+#pragma unroll 4
+    for (uint32_t rr = rsub; rr < nrows; rr += RPP, src += src_step, dst += dst_step) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src);
+        const uint64_t sw = (v.y >> 32) * 0x100000001ull;  // (the entry's sign word, twice)
+        oc_u128_a8 o;
+        o.x = is_hdr ? hdr : val_hi ? sw : v.x;
+        o.y = is_hdr ? v.x : val_hi ? sw : v.y;
+        *reinterpret_cast<oc_u128_a8 *>(dst) = o;
+    }
+}
+
 }  // namespace zipk

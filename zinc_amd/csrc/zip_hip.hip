@@ -48,6 +48,34 @@ struct PendingEvent {
 
 }  // namespace
 
+// (documented with get_hint_plan below)
+struct PackedLayout {
+    uint32_t stride = 0, off[3] = {};
+};
+struct HintPlan {
+    uint32_t cw = 0, e = 0, threads = 0;
+    bool want_packed = false;
+    std::vector<uint32_t> cols;
+    std::vector<uint32_t> bm;
+    bool packed = false;
+    PackedLayout L;
+    std::vector<uint32_t> wave_tab;  // [waves][phases][16] words = 32 16-bit bases each
+    std::vector<uint16_t> pos[4];    // 0xFFFF: not a member
+    // pk_rank of cs[i]: place of its value and of its three lowest siblings
+    bool ranks(const uint32_t *cs, uint32_t n, uint16_t *out) const {
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t col = cs[i];
+            if (col >= cw) return false;
+            const uint16_t r[4] = {pos[0][col], pos[1][col ^ 1u], pos[2][(col >> 1) ^ 1u], pos[3][(col >> 2) ^ 1u]};
+            for (int k = 0; k < 4; k++) {
+                if (r[k] == 0xFFFF) return false;
+                out[4 * i + k] = r[k];
+            }
+        }
+        return true;
+    }
+};
+
 struct zip_ctx {
     zip_params p{};
     uint32_t depth = 0;
@@ -73,6 +101,7 @@ struct zip_ctx {
     unsigned char *bounce[2] = {nullptr, nullptr};
     size_t bounce_cap = 0;
     std::vector<unsigned char *> hint_free;  // pinned kHintBytes blocks of dead hinted commitments
+    std::shared_ptr<HintPlan> hint_plan;  // what the last hinted commit derived from its column list (memo)
     // make_field memo: the last zip_field seen and what FieldConfig::new made of it (a HostField, kept as bytes here
     // because that type is defined further down)
     zip_field field_cache_in{};
@@ -121,11 +150,10 @@ struct zip_commitment {
     bool direct = false;  // zip_commit_open: values and level-0..2 siblings went into the proof, not into rows / layers ...
     uint32_t direct_from_row = 0;  // ... for the rows from this one on
     // zip_commit_open, packed openings: values and level-0..2 nodes of the hinted columns sit densely in `rows`
-    // (CommitArgs.pk); hint_bm = the four bitmaps V | N0 | N1 | N2 the ranks are taken from
+    // (CommitArgs.pk), at the positions `plan` holds
     bool packed = false;
     uint32_t pk_stride = 0, pk_off[3] = {};
-    std::vector<uint32_t> hint_bm;
-    std::vector<uint16_t> hint_pref;  // per word of hint_bm: set bits of ITS bitmap before that word
+    std::shared_ptr<HintPlan> plan;  // bitmaps, packed layout and the position of every member (HintPlan)
     const uint16_t *gather_rank = nullptr;  // device, valid during one open: OpenColsArgs.pk_rank
     std::vector<uint32_t> hint_cols;
     unsigned char *hint_h = nullptr;  // pinned staging of the bitmaps (returns to ctx->hint_free)
@@ -736,19 +764,19 @@ int32_t launch_commit(zip_ctx *ctx, const CommitArgs &a, uint32_t threads, uint3
 }
 
 // raa_commit16_kernel (t2 compacted into LDS, T threads x 16 entries): cw = 16384 with T = 1024, cw = 8192 with T = 512
-template <uint32_t T, bool HASH, bool MASKED = false>
+template <uint32_t T, bool HASH, int MODE = kStoreAll>
 int32_t launch_commit16_t(zip_ctx *ctx, const CommitArgs &a, uint32_t grid, hipStream_t st) {
-    auto kern = raa_commit16_kernel<T, HASH, MASKED>;
+    auto kern = raa_commit16_kernel<T, HASH, MODE>;
     if (int32_t rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), c16_lds_bytes(T))) return rc;
     LaunchTimer t(ctx, HASH ? "raa_commit_kernel" : "raa_encode_kernel", st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T), c16_lds_bytes(T), st, a);
     HIP_TRY(ctx, hipGetLastError());
     return ZIP_OK;
 }
-template <bool HASH, bool MASKED = false>
+template <bool HASH, int MODE = kStoreAll>
 int32_t launch_commit16(zip_ctx *ctx, const CommitArgs &a, uint32_t grid, hipStream_t st) {
-    return a.cw == 16384 ? launch_commit16_t<1024, HASH, MASKED>(ctx, a, grid, st)
-                         : launch_commit16_t<512, HASH, MASKED>(ctx, a, grid, st);
+    return a.cw == 16384 ? launch_commit16_t<1024, HASH, MODE>(ctx, a, grid, st)
+                         : launch_commit16_t<512, HASH, MODE>(ctx, a, grid, st);
 }
 
 struct CommitGeom {
@@ -803,70 +831,99 @@ bool commit_supports_direct(const zip_ctx *ctx, uint32_t n_cols) {
     return g.lds + direct_lds_bytes(n_cols) + 64 <= 160u * 1024u;
 }
 
-// ---- packed openings (CommitArgs.pk) --------------------------------------------------------------------------
-// Number of set bits of a bitmap below index i.
-static uint32_t bits_below(const uint32_t *bm, uint32_t i) {
-    uint32_t n = 0;
-    for (uint32_t w = 0; w < (i >> 5); w++) n += (uint32_t)__builtin_popcount(bm[w]);
-    if (i & 31u) n += (uint32_t)__builtin_popcount(bm[i >> 5] & ((1u << (i & 31u)) - 1u));
-    return n;
+// ---- opening hints and packed openings (CommitArgs.need / .pk) -------------------------------------------------
+// Everything a hinted commit derives from its column list, kept per ctx until the list changes (in the prover flow it
+// never does: a fresh PcsTranscript squeezes the same columns for every proof, zinc/prover.rs:316).
+//   bm         the four bitmaps V | N0 (cw bits each) | N1 (cw / 2) | N2 (cw / 4): entries opened, level-0..2 nodes
+//              that are some opening's sibling
+//   packed     the commit kernel of this geometry can store those members densely (CommitArgs.pk); then
+//   pos[s][i]  = the place of member i in section s of a row's packed block, and wave_tab = CommitArgs.pk_tab.
+// The place of a member is its turn in the enumeration  wave -> output phase -> store site -> lane class -> lane
+// of the kernel's lanes (StridedLeaves: entry of step e = e * sT + stid(lane); level-1 node of group g at lane
+// parity p = ((2g + p) sT + stid) >> 1; level-2 node of group g at lane mod 4 = c = ((4g + c) sT + stid) >> 2): the
+// kernel recovers it as a per-wave base (wave_tab) + the number of storing lanes of the class below it.  For the
+// 8-entries-per-thread kernel that enumeration is plain index order.
+static bool packed_enabled() {
+    const char *e = getenv("ZIP_HIP_PACKED");  // (read per call: the tests flip it)
+    return !(e && atoi(e) == 0);
 }
-struct PackedLayout {
-    uint32_t stride = 0, off[3] = {};
-};
-// bm = V | N0 (cw bits each) | N1 (cw / 2) | N2 (cw / 4), as commit_impl builds them
-static PackedLayout packed_layout(const uint32_t *bm, uint32_t cw) {
-    const uint32_t wv = (cw + 31) / 32, w1 = (cw / 2 + 31) / 32;
-    const uint32_t *nv = bm, *n0 = nv + wv, *n1 = n0 + wv, *n2 = n1 + w1;
-    PackedLayout L;
-    uint32_t at = (bits_below(nv, cw) * 16u + 127u) & ~127u;
-    L.off[0] = at;
-    at = (at + bits_below(n0, cw) * 32u + 127u) & ~127u;
-    L.off[1] = at;
-    at = (at + bits_below(n1, cw / 2) * 32u + 127u) & ~127u;
-    L.off[2] = at;
-    at = (at + bits_below(n2, cw / 4) * 32u + 127u) & ~127u;
-    L.stride = at;
-    return L;
-}
-// CommitArgs.pk_tab: per wave w of the T = cw / 8 threads, 32 ranks (two per word): V and N0 of step e at
-// e * T + 64 w; N1 of group g, parity p at g * T + p * T / 2 + 32 w; N2 of group g, tid mod 4 = q at
-// g * T + q * T / 4 + 16 w -- the first index the wave's lanes own at that store site (StridedLeaves)
-static void packed_wave_table(const uint32_t *bm, uint32_t cw, uint32_t *tab) {
-    const uint32_t T = cw / 8, waves = T / 64, wv = (cw + 31) / 32, w1 = (cw / 2 + 31) / 32;
-    const uint32_t *nv = bm, *n0 = nv + wv, *n1 = n0 + wv, *n2 = n1 + w1;
-    // prefix counts at multiples of 16 are all this needs
-    auto prefix16 = [](const uint32_t *b, uint32_t bits) {
-        std::vector<uint16_t> p(bits / 16 + 1);
-        uint32_t n = 0;
-        for (uint32_t i = 0; i <= bits / 16; i++) {
-            p[i] = (uint16_t)n;
-            if (i < bits / 16) n += (uint32_t)__builtin_popcount((b[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu);
+static void plan_packed(HintPlan &P) {
+    const uint32_t cw = P.cw, wv = (cw + 31) / 32, w1 = (cw / 2 + 31) / 32;
+    const uint32_t *sec[4] = {P.bm.data(), P.bm.data() + wv, P.bm.data() + 2 * wv, P.bm.data() + 2 * wv + w1};
+    const uint32_t bits[4] = {cw, cw, cw / 2, cw / 4};
+    const uint32_t waves = P.threads / 64, phases = P.e == 16 ? 2 : 1, sT = P.e == 16 ? 16 : P.threads;
+    for (int k = 0; k < 4; k++) P.pos[k].assign(bits[k], 0xFFFF);
+    P.wave_tab.assign((size_t)waves * phases * 16, 0);
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    auto member = [&](int k, uint32_t i) { return (sec[k][i >> 5] >> (i & 31u)) & 1u; };
+    for (uint32_t w = 0; w < waves; w++)
+        for (uint32_t q = 0; q < phases; q++) {
+            uint16_t base[32];
+            auto stid = [&](uint32_t l) {
+                const uint32_t tid = 64 * w + l;
+                return P.e == 16 ? (tid & ~7u) * 16u + q * 8u + (tid & 7u) : tid;
+            };
+            auto site = [&](int k, int slot, uint32_t step, uint32_t shift, uint32_t cls, uint32_t ncls) {
+                base[slot] = (uint16_t)cnt[k];
+                for (uint32_t l = cls; l < 64; l += ncls) {
+                    const uint32_t i = (step * sT + stid(l)) >> shift;
+                    if (member(k, i)) P.pos[k][i] = (uint16_t)cnt[k]++;
+                }
+            };
+            for (uint32_t e = 0; e < 8; e++) site(0, (int)e, e, 0, 0, 1);
+            for (uint32_t e = 0; e < 8; e++) site(1, (int)(8 + e), e, 0, 0, 1);
+            for (uint32_t g = 0; g < 4; g++)
+                for (uint32_t par = 0; par < 2; par++) site(2, (int)(16 + 2 * g + par), 2 * g + par, 1, par, 2);
+            for (uint32_t g = 0; g < 2; g++)
+                for (uint32_t c4 = 0; c4 < 4; c4++) site(3, (int)(24 + 4 * g + c4), 4 * g + c4, 2, c4, 4);
+            uint32_t *tab = P.wave_tab.data() + ((size_t)w * phases + q) * 16;
+            for (uint32_t k = 0; k < 16; k++) tab[k] = (uint32_t)base[2 * k] | ((uint32_t)base[2 * k + 1] << 16);
         }
-        return p;
-    };
-    const std::vector<uint16_t> pv = prefix16(nv, cw), p0 = prefix16(n0, cw), p1 = prefix16(n1, cw / 2), p2 = prefix16(n2, cw / 4);
-    for (uint32_t w = 0; w < waves; w++) {
-        uint16_t v[32];
-        for (uint32_t e = 0; e < 8; e++) {
-            v[e] = pv[(e * T + 64 * w) / 16];
-            v[8 + e] = p0[(e * T + 64 * w) / 16];
-        }
-        for (uint32_t g = 0; g < 4; g++)
-            for (uint32_t par = 0; par < 2; par++) v[16 + 2 * g + par] = p1[(g * T + par * (T / 2) + 32 * w) / 16];
-        for (uint32_t g = 0; g < 2; g++)
-            for (uint32_t q = 0; q < 4; q++) v[24 + 4 * g + q] = p2[(g * T + q * (T / 4) + 16 * w) / 16];
-        for (uint32_t k = 0; k < 16; k++) tab[w * 16 + k] = (uint32_t)v[2 * k] | ((uint32_t)v[2 * k + 1] << 16);
-    }
+    uint32_t at = (cnt[0] * 16u + 127u) & ~127u;
+    P.L.off[0] = at;
+    at = (at + cnt[1] * 32u + 127u) & ~127u;
+    P.L.off[1] = at;
+    at = (at + cnt[2] * 32u + 127u) & ~127u;
+    P.L.off[2] = at;
+    at = (at + cnt[3] * 32u + 127u) & ~127u;
+    P.L.stride = at;
 }
-// zip_commit_open stores the low part of the openings packed where the commit kernel has the variant (8 entries per
-// thread, whole waves) and the packed rows fit the buffer of the 16-byte row entries they replace
-static bool commit_supports_packed(const zip_ctx *ctx, const PackedLayout &L) {
-    { const char *e = getenv("ZIP_HIP_PACKED"); if (e && atoi(e) == 0) return false; }  // (read per call: the tests flip it)
+// zip_commit_open stores the low part of the openings packed where the commit kernel has the variant (whole waves of
+// 8 or 16 entries per thread, depth >= 3) and the packed rows fit the buffer of the 16-byte row entries they replace
+static std::shared_ptr<HintPlan> get_hint_plan(zip_ctx *ctx, const uint32_t *cols, uint32_t n_cols, bool want_packed) {
     const uint32_t cw = ctx->p.codeword_len;
     const CommitGeom g = commit_geom(cw, ctx->p.row_len);
-    if (g.e != 8 || cw < 512 || g.threads != cw / 8 || ctx->depth < 3) return false;
-    return L.stride > 0 && (size_t)L.stride <= (size_t)cw * 16 && (size_t)(cw / 8 / 64) * 64 <= kHintBytes - kHintTables;
+    if (ctx->hint_plan) {
+        const HintPlan &h = *ctx->hint_plan;
+        if (h.cw == cw && h.e == g.e && h.threads == g.threads && h.want_packed == want_packed && h.cols.size() == n_cols &&
+            (n_cols == 0 || !memcmp(h.cols.data(), cols, (size_t)n_cols * 4)))
+            return ctx->hint_plan;
+    }
+    auto P = std::make_shared<HintPlan>();
+    P->cw = cw;
+    P->e = g.e;
+    P->threads = g.threads;
+    P->want_packed = want_packed;
+    P->cols.assign(cols, cols + n_cols);
+    const uint32_t wv = (cw + 31) / 32, w1 = (cw / 2 + 31) / 32, w2 = (cw / 4 + 31) / 32;
+    P->bm.assign(2 * (size_t)wv + w1 + w2, 0);
+    uint32_t *nv = P->bm.data(), *n0 = nv + wv, *n1 = n0 + wv, *n2 = n1 + w1;
+    for (uint32_t i = 0; i < n_cols; i++) {
+        const uint32_t col = cols[i];
+        nv[col >> 5] |= 1u << (col & 31);
+        const uint32_t s0 = col ^ 1u, s1 = (col >> 1) ^ 1u, s2 = (col >> 2) ^ 1u;
+        n0[s0 >> 5] |= 1u << (s0 & 31);
+        n1[s1 >> 5] |= 1u << (s1 & 31);
+        n2[s2 >> 5] |= 1u << (s2 & 31);
+    }
+    if (want_packed && n_cols && (g.e == 8 || g.e == 16) && cw >= 512 && g.threads % 64 == 0 && cw == g.e * g.threads &&
+        ctx->depth >= 3) {
+        plan_packed(*P);
+        P->packed = P->L.stride > 0 && (size_t)P->L.stride <= (size_t)cw * 16 &&
+                    P->wave_tab.size() * 4 <= kHintBytes - kHintTables;
+    }
+    ctx->hint_plan = P;
+    return P;
 }
 
 template <bool HASH>
@@ -877,8 +934,9 @@ int32_t dispatch_commit(zip_ctx *ctx, CommitArgs a, uint32_t grid, hipStream_t s
         if (g.e == 8 && a.open_cols) return launch_commit<8, HASH, HASH ? kStoreDirect : kStoreAll>(ctx, a, g.threads, grid, st);
         a.open_cols = nullptr;
         if (g.e == 8 && a.pk) return launch_commit<8, HASH, HASH ? kStorePacked : kStoreAll>(ctx, a, g.threads, grid, st);
+        if (g.e == 16 && a.pk) return launch_commit16<HASH, HASH ? kStorePacked : kStoreAll>(ctx, a, grid, st);
         a.pk = nullptr;
-        if (g.e == 16) return launch_commit16<HASH, HASH>(ctx, a, grid, st);
+        if (g.e == 16) return launch_commit16<HASH, HASH ? kStoreHinted : kStoreAll>(ctx, a, grid, st);
         if (g.e == 8) return launch_commit<8, HASH, HASH ? kStoreHinted : kStoreAll>(ctx, a, g.threads, grid, st);
         a.need = nullptr;
     }
@@ -1140,6 +1198,22 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
     static const int knob_prio = getenv("ZIP_HIP_GATHER_PRIO") ? atoi(getenv("ZIP_HIP_GATHER_PRIO")) : 1;
     a.prio = (uint32_t)knob_prio;
     a.skip_low = skip_low;
+    // The whole opening (skip_low == 0) where the commit kernel leaves little LDS (cw = 16384: 16 records per workgroup):
+    // the kernel without an LDS image.  ZIP_HIP_GATHER_STREAM=1 / 0 forces it on / off.
+    static const int knob_stream = getenv("ZIP_HIP_GATHER_STREAM") ? atoi(getenv("ZIP_HIP_GATHER_STREAM")) : -1;
+    const bool stream = knob_stream >= 0 ? knob_stream == 1 : rpb < 32;
+    if (stream && skip_low == 0 && ctx->depth >= 1 && 2 * ctx->depth + 3 <= 64) {
+        const uint32_t want = (knob_rpb >= 2 && knob_rpb <= 4096) ? knob_rpb : 32u;
+        a.rows_per_block = (row_hi - row_lo) < want ? (row_hi - row_lo) : want;
+        const dim3 grid(n_cols, (row_hi - row_lo + a.rows_per_block - 1) / a.rows_per_block), block(256);
+        LaunchTimer t(ctx, "open_columns_kernel");
+        if (2 * ctx->depth + 3 <= 32)
+            hipLaunchKernelGGL(open_columns_stream_kernel<32>, grid, block, 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(open_columns_stream_kernel<64>, grid, block, 0, ctx->stream, a);
+        HIP_TRY(ctx, hipGetLastError());
+        return ZIP_OK;
+    }
     const size_t lds = (size_t)a.rows_per_block * (8 + 32 * (size_t)(ctx->depth - skip_low));
     const dim3 grid(n_cols, (row_hi - row_lo + a.rows_per_block - 1) / a.rows_per_block), block(256);
     LaunchTimer t(ctx, "open_columns_kernel");
@@ -1909,39 +1983,20 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
                 rc = fail(ctx, ZIP_ERR_ALLOC, "hipHostMalloc(%zu) failed", kHintBytes);
                 break;
             }
+            const bool direct = open_cols_d && commit_supports_direct(ctx, n_hint);
+            const bool want_packed = open_cols_d && !direct && c->compact_rows && n_hint && packed_enabled();
+            c->plan = get_hint_plan(ctx, hint_cols, n_hint, want_packed);
             uint32_t *bm = reinterpret_cast<uint32_t *>(c->hint_h);
-            memset(bm, 0, words * 4);
-            uint32_t *nv = bm, *n0 = nv + wv, *n1 = n0 + wv, *n2 = n1 + w1;
-            for (uint32_t i = 0; i < n_hint; i++) {
-                const uint32_t col = hint_cols[i];
-                nv[col >> 5] |= 1u << (col & 31);
-                const uint32_t s0 = col ^ 1u, s1 = (col >> 1) ^ 1u, s2 = (col >> 2) ^ 1u;
-                n0[s0 >> 5] |= 1u << (s0 & 31);
-                n1[s1 >> 5] |= 1u << (s1 & 31);
-                n2[s2 >> 5] |= 1u << (s2 & 31);
-            }
+            memcpy(bm, c->plan->bm.data(), words * 4);
+            const uint32_t *nv = bm;
             c->hint_cols.assign(nv, nv + wv);
             size_t upload = words * 4;
-            const bool direct = open_cols_d && commit_supports_direct(ctx, n_hint);
-            if (open_cols_d && !direct && c->compact_rows && n_hint) {
-                const PackedLayout L = packed_layout(bm, cw);
-                if (commit_supports_packed(ctx, L)) {
-                    packed_wave_table(bm, cw, reinterpret_cast<uint32_t *>(c->hint_h + kHintTables));
-                    upload = kHintTables + (size_t)(cw / 8 / 64) * 64;
-                    c->packed = true;
-                    c->pk_stride = L.stride;
-                    for (int k = 0; k < 3; k++) c->pk_off[k] = L.off[k];
-                    c->hint_bm.assign(bm, bm + words);
-                    c->hint_pref.resize(words);
-                    const size_t starts[5] = {0, wv, 2 * (size_t)wv, 2 * (size_t)wv + w1, words};
-                    for (int b = 0; b < 4; b++) {
-                        uint32_t n = 0;
-                        for (size_t w = starts[b]; w < starts[b + 1]; w++) {
-                            c->hint_pref[w] = (uint16_t)n;
-                            n += (uint32_t)__builtin_popcount(bm[w]);
-                        }
-                    }
-                }
+            if (c->plan->packed) {
+                memcpy(c->hint_h + kHintTables, c->plan->wave_tab.data(), c->plan->wave_tab.size() * 4);
+                upload = kHintTables + c->plan->wave_tab.size() * 4;
+                c->packed = true;
+                c->pk_stride = c->plan->L.stride;
+                for (int k = 0; k < 3; k++) c->pk_off[k] = c->plan->L.off[k];
             }
             if (direct) {
                 // column -> openings lists (CommitArgs.open_tab): vp[cw / 32] | firstr[n] | next[n]
@@ -2360,23 +2415,9 @@ static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int6
     }
     std::vector<uint16_t> ranks;
     if (c->packed) {  // where each opening finds its value and its three lowest siblings in a row's packed block
-        const uint32_t cw = ctx->p.codeword_len, wv = (cw + 31) / 32, w1 = (cw / 2 + 31) / 32;
-        const uint32_t *bmw = c->hint_bm.data();
-        const uint16_t *pref = c->hint_pref.data();
-        const uint32_t start[4] = {0, wv, 2 * wv, 2 * wv + w1};  // first word of V, N0, N1, N2
-        auto rank = [&](int b, uint32_t i) {
-            const uint32_t w = start[b] + (i >> 5);
-            return (uint16_t)(pref[w] + (uint32_t)__builtin_popcount(bmw[w] & ((1u << (i & 31u)) - 1u)));
-        };
         ranks.resize((size_t)n_cols * 4);
-        for (uint32_t i = 0; i < n_cols; i++) {
-            const uint32_t col = cols[i];
-            if (!((bmw[col >> 5] >> (col & 31u)) & 1u)) return fail(ctx, ZIP_ERR_INVALID_PARAM, "column %u is not in the commit's hint", col);
-            ranks[4 * i] = rank(0, col);
-            ranks[4 * i + 1] = rank(1, col ^ 1u);
-            ranks[4 * i + 2] = rank(2, (col >> 1) ^ 1u);
-            ranks[4 * i + 3] = rank(3, (col >> 2) ^ 1u);
-        }
+        if (!c->plan || !c->plan->ranks(cols, n_cols, ranks.data()))
+            return fail(ctx, ZIP_ERR_INVALID_PARAM, "an opened column is not in the commit's hint");
         si.src[4] = ranks.data();
         si.bytes[4] = ranks.size() * 2;
     }
