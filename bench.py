@@ -388,9 +388,8 @@ def main():
         achieved = commit_bytes / (avg_ms * 1e-3) / 1e9
         direct = (not args.no_hint and not args.two_calls and 512 <= cw <= 8192
                   and os.environ.get("ZIP_HIP_DIRECT") == "1")  # commit_supports_direct (zip_hip.hip)
-        # commit_supports_packed (zip_hip.hip): the 8-entries-per-thread kernel, one call
-        packed = (not args.no_hint and not args.two_calls and not direct and 512 <= cw <= 8192
-                  and os.environ.get("ZIP_HIP_PACKED") != "0")
+        # get_hint_plan (zip_hip.hip): every hinted commit of the 8- and 16-entries-per-thread kernels
+        packed = not args.no_hint and not direct and cw >= 512 and os.environ.get("ZIP_HIP_PACKED") != "0"
         mode = "plain" if args.no_hint else "direct" if direct else "packed" if packed else "hinted"
         moved = commit_moved_bytes(per, row_len, cw, depth, None if args.no_hint else cols, direct)
         pe = pmc_entry(dom, nv, mode) if not rows_mode else None
@@ -425,7 +424,9 @@ def main():
                        "parallelism": ("rows%d" % world if rows_mode else "polys%d" % world),
                        "commit": ("zip_commit + zip_open (everything stored)" if args.no_hint else
                                   "zip_commit_hinted + zip_open (the 1000 columns are known before the commit, "
-                                  "prover.rs:316; stores no opening reads are skipped)" if args.two_calls else
+                                  "prover.rs:316; stores no opening reads are skipped%s)"
+                                  % ("; what the openings read of the entries and of tree levels 0..2 is stored packed"
+                                     if packed else "") if args.two_calls else
                                   "zip_commit_open (one call, as commit_z_mle_and_prove_evaluation: the 1000 columns are "
                                   "known before the commit, prover.rs:316; stores no opening reads are skipped%s)"
                                   % ("; ZIP_HIP_DIRECT=1: values and the three lowest siblings go straight into the proof"

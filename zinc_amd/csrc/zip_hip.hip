@@ -61,6 +61,7 @@ struct HintPlan {
     PackedLayout L;
     std::vector<uint32_t> wave_tab;  // [waves][phases][16] words = 32 16-bit bases each
     std::vector<uint16_t> pos[4];    // 0xFFFF: not a member
+    std::vector<uint16_t> own_ranks; // pk_rank of cols[] themselves, [n][4] (uploaded with the hint: OpenColsArgs.pk_rank)
     // pk_rank of cs[i]: place of its value and of its three lowest siblings
     bool ranks(const uint32_t *cs, uint32_t n, uint16_t *out) const {
         for (uint32_t i = 0; i < n; i++) {
@@ -154,7 +155,7 @@ struct zip_commitment {
     bool packed = false;
     uint32_t pk_stride = 0, pk_off[3] = {};
     std::shared_ptr<HintPlan> plan;  // bitmaps, packed layout and the position of every member (HintPlan)
-    const uint16_t *gather_rank = nullptr;  // device, valid during one open: OpenColsArgs.pk_rank
+    const uint16_t *rank_d = nullptr;  // device (inside need_d): OpenColsArgs.pk_rank of the hinted openings, in their order
     std::vector<uint32_t> hint_cols;
     unsigned char *hint_h = nullptr;  // pinned staging of the bitmaps (returns to ctx->hint_free)
     uint32_t *need_d = nullptr;       // device bitmaps (CommitArgs.need)
@@ -810,7 +811,8 @@ uint32_t commit_wgs_per_cu(const CommitGeom &g) {
 bool commit_supports_hint(uint32_t cw) { return cw >= 512; }
 // one pinned / device block per hinted commit: the bitmaps (<= 5.6 KB for cw <= 16384) at offset 0, the
 // column -> openings tables of zip_commit_open (first[cw] | next[n_cols], u16) at kHintTables
-constexpr size_t kHintTables = 8192, kHintBytes = kHintTables + 8 * (8192 / 32) + 4 * 4096 + 64;
+// (packed openings: the wave table at kHintTables, the ranks of the hinted openings at kPackedRanksAt)
+constexpr size_t kHintTables = 8192, kHintBytes = kHintTables + 8 * (8192 / 32) + 4 * 4096 + 64, kPackedRanksAt = kHintTables + 2048;
 constexpr uint32_t kDirectMaxCols = 4096;
 // zip_commit_open writes the low part of the openings from the commit kernel where that kernel has the variant
 // (8 entries per thread) and room in LDS for the tables; elsewhere it is zip_commit_hinted + the whole gather
@@ -919,8 +921,9 @@ static std::shared_ptr<HintPlan> get_hint_plan(zip_ctx *ctx, const uint32_t *col
     if (want_packed && n_cols && (g.e == 8 || g.e == 16) && cw >= 512 && g.threads % 64 == 0 && cw == g.e * g.threads &&
         ctx->depth >= 3) {
         plan_packed(*P);
-        P->packed = P->L.stride > 0 && (size_t)P->L.stride <= (size_t)cw * 16 &&
-                    P->wave_tab.size() * 4 <= kHintBytes - kHintTables;
+        P->own_ranks.resize((size_t)n_cols * 4);
+        P->packed = P->L.stride > 0 && (size_t)P->L.stride <= (size_t)cw * 16 && P->wave_tab.size() * 4 <= kPackedRanksAt - kHintTables &&
+                    kPackedRanksAt + P->own_ranks.size() * 2 <= kHintBytes && P->ranks(cols, n_cols, P->own_ranks.data());
     }
     ctx->hint_plan = P;
     return P;
@@ -1160,13 +1163,13 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
     a.cols = cols_dv;
     a.order = c->gather_order;
     if (c->packed) {
-        if (!c->gather_rank) return fail(ctx, ZIP_ERR_INVALID_PARAM, "packed commitment opened without its rank table");
+        if (!c->rank_d) return fail(ctx, ZIP_ERR_INVALID_PARAM, "packed commitment without its rank table");
         a.pk = reinterpret_cast<const uint8_t *>(c->rows);
         a.pk_stride = c->pk_stride;
         a.pk_off0 = c->pk_off[0];
         a.pk_off1 = c->pk_off[1];
         a.pk_off2 = c->pk_off[2];
-        a.pk_rank = c->gather_rank;
+        a.pk_rank = c->rank_d;
     }
     a.out = out_d;
     a.num_rows = ctx->rows_local;
@@ -1867,6 +1870,7 @@ void *zip_ctx_stream(zip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr;
 static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
                            int32_t with_merkle, const uint32_t *hint_cols, uint32_t n_hint, uint8_t *roots_out,
                            zip_commitment **out, uint8_t *open_cols_d = nullptr) {
+    // (open_cols_d: zip_commit_open's proof stream, for the opt-in direct mode)
     if (!ctx || !out) return ZIP_ERR_NULL;
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1984,7 +1988,7 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
                 break;
             }
             const bool direct = open_cols_d && commit_supports_direct(ctx, n_hint);
-            const bool want_packed = open_cols_d && !direct && c->compact_rows && n_hint && packed_enabled();
+            const bool want_packed = !direct && c->compact_rows && n_hint && packed_enabled();
             c->plan = get_hint_plan(ctx, hint_cols, n_hint, want_packed);
             uint32_t *bm = reinterpret_cast<uint32_t *>(c->hint_h);
             memcpy(bm, c->plan->bm.data(), words * 4);
@@ -1993,7 +1997,8 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
             size_t upload = words * 4;
             if (c->plan->packed) {
                 memcpy(c->hint_h + kHintTables, c->plan->wave_tab.data(), c->plan->wave_tab.size() * 4);
-                upload = kHintTables + c->plan->wave_tab.size() * 4;
+                memcpy(c->hint_h + kPackedRanksAt, c->plan->own_ranks.data(), c->plan->own_ranks.size() * 2);
+                upload = kPackedRanksAt + c->plan->own_ranks.size() * 2;
                 c->packed = true;
                 c->pk_stride = c->plan->L.stride;
                 for (int k = 0; k < 3; k++) c->pk_off[k] = c->plan->L.off[k];
@@ -2028,6 +2033,7 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
                 a.pk_off1 = c->pk_off[1];
                 a.pk_off2 = c->pk_off[2];
                 a.pk_tab = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(c->need_d) + kHintTables);
+                c->rank_d = reinterpret_cast<const uint16_t *>(reinterpret_cast<const unsigned char *>(c->need_d) + kPackedRanksAt);
             }
             if (direct) {
                 const uint32_t rec = 8 + 32 * ctx->depth;
@@ -2126,7 +2132,10 @@ static int32_t rematerialize(zip_commitment *c) {
 static int32_t ensure_columns(zip_commitment *c, const uint32_t *cols, uint32_t n_cols) {
     if (!c->hinted) return ZIP_OK;
     if (c->direct) return rematerialize(c);  // the low levels of the hinted columns only exist in that call's proof
-    if (c->packed) return rematerialize(c);  // ... or in the packed blocks only the one call that made them reads
+    // ... a packed handle serves the openings it was hinted with, in their order (rank_d); anything else completes it
+    if (c->packed)
+        return (c->plan && c->plan->cols.size() == n_cols && (n_cols == 0 || !memcmp(c->plan->cols.data(), cols, (size_t)n_cols * 4)))
+                   ? ZIP_OK : rematerialize(c);
     for (uint32_t i = 0; i < n_cols; i++) {
         const uint32_t col = cols[i];
         if ((col >> 5) >= c->hint_cols.size() || !((c->hint_cols[col >> 5] >> (col & 31)) & 1u)) return rematerialize(c);
@@ -2413,22 +2422,13 @@ static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int6
         si.src[3] = order.data();
         si.bytes[3] = (size_t)n_cols * 4;
     }
-    std::vector<uint16_t> ranks;
-    if (c->packed) {  // where each opening finds its value and its three lowest siblings in a row's packed block
-        ranks.resize((size_t)n_cols * 4);
-        if (!c->plan || !c->plan->ranks(cols, n_cols, ranks.data()))
-            return fail(ctx, ZIP_ERR_INVALID_PARAM, "an opened column is not in the commit's hint");
-        si.src[4] = ranks.data();
-        si.bytes[4] = ranks.size() * 2;
-    }
     unsigned char *sb;
     if ((rc = stage_small(ctx, si, small, &sb))) return rc;
     struct OrderScope {  // the tables live in `small`: no launch may see them after this call
         zip_commitment *c;
-        ~OrderScope() { c->gather_order = nullptr; c->gather_rank = nullptr; }
+        ~OrderScope() { c->gather_order = nullptr; }
     } order_scope{c};
     c->gather_order = order.empty() ? nullptr : reinterpret_cast<const uint32_t *>(sb + si.off[3]);
-    c->gather_rank = ranks.empty() ? nullptr : reinterpret_cast<const uint16_t *>(sb + si.off[4]);
     // The two row combinations do not depend on the commitment.  Where to put them (ZIP_HIP_COMBINE):
     //   split (default) the pass over the witness FIRST on the main stream -- the stream would otherwise idle until the
     //                   commit kernel publishes its first chunk, and with s_setprio the pass is not starved by the
