@@ -123,8 +123,10 @@ void zip_commitment_free(zip_commitment *c);
  * cols: HOST, n_cols indices < codeword_len (duplicates allowed).
  * Same roots and the same handle semantics as zip_commit; the hint only lets the commit kernel skip the HBM
  * stores no opening of those columns can read (about three quarters of the encoded rows and tree nodes at 1000
- * of 8192 columns).  Whatever else is later asked of the handle -- other columns, zip_commit_download, the rows /
- * layers device pointers -- first re-runs the commit in full from the witness, transparently; for that a DEVICE
+ * of 8192 columns) and put what they do read of the entries and of tree levels 0..2 into one dense block per row.
+ * Whatever else is later asked of the handle -- an opening of any other column list (codeword_len >= 512: of
+ * anything but exactly `cols`, in that order), zip_commit_download, the rows / layers device pointers -- first
+ * re-runs the commit in full from the witness, transparently; for that a DEVICE
  * `evals` must stay valid and unchanged until the handle is freed.  Geometries below codeword_len 512 ignore
  * the hint. */
 int32_t zip_commit_hinted(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
