@@ -61,7 +61,13 @@ struct HintPlan {
     PackedLayout L;
     std::vector<uint32_t> wave_tab;  // [waves][phases][16] words = 32 16-bit bases each
     std::vector<uint16_t> pos[4];    // 0xFFFF: not a member
-    std::vector<uint16_t> own_ranks; // pk_rank of cols[] themselves, [n][4] (uploaded with the hint: OpenColsArgs.pk_rank)
+    std::vector<uint16_t> own_ranks; // pk_rank of cols[] themselves, [n][4] (OpenColsArgs.pk_rank)
+    // device copy, made once: bm at 0 (CommitArgs.need), wave_tab at kHintTables, own_ranks at kPackedRanksAt
+    unsigned char *dev = nullptr;
+    HintPlan() = default;
+    HintPlan(const HintPlan &) = delete;
+    HintPlan &operator=(const HintPlan &) = delete;
+    ~HintPlan() { if (dev) (void)hipFree(dev); }
     // pk_rank of cs[i]: place of its value and of its three lowest siblings
     bool ranks(const uint32_t *cs, uint32_t n, uint16_t *out) const {
         for (uint32_t i = 0; i < n; i++) {
@@ -103,6 +109,11 @@ struct zip_ctx {
     size_t bounce_cap = 0;
     std::vector<unsigned char *> hint_free;  // pinned kHintBytes blocks of dead hinted commitments
     std::shared_ptr<HintPlan> hint_plan;  // what the last hinted commit derived from its column list (memo)
+    // chunk arrival counters of the persistent commit kernel: kRingSlots zeroed blocks of kRingStride counters, handed
+    // out in turn; every kRingSlots commits the ring is zeroed again (ring_epoch moves: an older handle's counters
+    // are gone, its openings then wait for the whole commit instead)
+    uint32_t *ring_d = nullptr;
+    uint32_t ring_next = 0, ring_epoch = 0;
     // make_field memo: the last zip_field seen and what FieldConfig::new made of it (a HostField, kept as bytes here
     // because that type is defined further down)
     zip_field field_cache_in{};
@@ -140,7 +151,9 @@ struct zip_commitment {
     // Pipeline state of the persistent commit kernel that produces this handle: chunk k = rows
     // [bounds[k], bounds[k+1]) is complete (rows, trees, roots) once chunk_done[k] == expected[k].
     std::vector<uint32_t> bounds, expected;
-    uint32_t *chunk_done = nullptr;  // device arrival counters
+    uint32_t *chunk_done = nullptr;  // device arrival counters (a pool block, or a slot of the ctx's ring)
+    bool ring_slot = false;
+    uint32_t ring_epoch = 0;
     hipEvent_t zeroed = nullptr;     // counters reset (consumers must not look at stale values)
     hipEvent_t done = nullptr;       // whole commit finished
     std::vector<hipEvent_t> aux;     // other events owned by the handle, recycled with it
@@ -812,6 +825,7 @@ bool commit_supports_hint(uint32_t cw) { return cw >= 512; }
 // one pinned / device block per hinted commit: the bitmaps (<= 5.6 KB for cw <= 16384) at offset 0, the
 // column -> openings tables of zip_commit_open (first[cw] | next[n_cols], u16) at kHintTables
 // (packed openings: the wave table at kHintTables, the ranks of the hinted openings at kPackedRanksAt)
+constexpr uint32_t kRingSlots = 64, kRingStride = 8;  // zip_ctx::ring_d
 constexpr size_t kHintTables = 8192, kHintBytes = kHintTables + 8 * (8192 / 32) + 4 * 4096 + 64, kPackedRanksAt = kHintTables + 2048;
 constexpr uint32_t kDirectMaxCols = 4096;
 // zip_commit_open writes the low part of the openings from the commit kernel where that kernel has the variant
@@ -924,6 +938,24 @@ static std::shared_ptr<HintPlan> get_hint_plan(zip_ctx *ctx, const uint32_t *col
         P->own_ranks.resize((size_t)n_cols * 4);
         P->packed = P->L.stride > 0 && (size_t)P->L.stride <= (size_t)cw * 16 && P->wave_tab.size() * 4 <= kPackedRanksAt - kHintTables &&
                     kPackedRanksAt + P->own_ranks.size() * 2 <= kHintBytes && P->ranks(cols, n_cols, P->own_ranks.data());
+    }
+    // the tables go to the device here, once, not with every commit
+    std::vector<unsigned char> img(kHintBytes, 0);
+    memcpy(img.data(), P->bm.data(), P->bm.size() * 4);
+    size_t used = P->bm.size() * 4;
+    if (P->packed) {
+        memcpy(img.data() + kHintTables, P->wave_tab.data(), P->wave_tab.size() * 4);
+        memcpy(img.data() + kPackedRanksAt, P->own_ranks.data(), P->own_ranks.size() * 2);
+        used = kPackedRanksAt + P->own_ranks.size() * 2;
+    }
+    if (used <= kHintBytes && hipMalloc((void **)&P->dev, kHintBytes) == hipSuccess) {
+        if (hipMemcpy(P->dev, img.data(), used, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(P->dev);
+            P->dev = nullptr;
+        }
+    } else {
+        P->dev = nullptr;
+        (void)hipGetLastError();
     }
     ctx->hint_plan = P;
     return P;
@@ -1233,7 +1265,7 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
 int32_t run_open_columns_pipelined(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d,
                                    uint32_t skip_low = 0) {
     zip_ctx *ctx = c->ctx;
-    if (!c->chunk_done) {
+    if (!c->chunk_done || (c->ring_slot && c->ring_epoch != ctx->ring_epoch)) {
         int32_t rc = wait_ready(c, ctx->stream);
         if (rc) return rc;
         if (skip_low && c->direct_from_row) {
@@ -1242,7 +1274,7 @@ int32_t run_open_columns_pipelined(zip_commitment *c, const uint32_t *cols_dv, u
         }
         return run_open_columns(c, cols_dv, n_cols, out_d, 0, ctx->rows_local, skip_low);
     }
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, c->zeroed, 0));
+    if (c->zeroed) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, c->zeroed, 0));
     // test hook: an unreachable target and a 1 ms limit exercise the recovery path of a timed-out wait
     const bool force_timeout = getenv("ZIP_HIP_FORCE_WAIT_TIMEOUT") != nullptr;
     for (size_t k = 0; k + 1 < c->bounds.size(); k++) {
@@ -1831,6 +1863,8 @@ void zip_ctx_destroy(zip_ctx *ctx) {
     if (ctx->s_aux) (void)hipStreamDestroy(ctx->s_aux);
     if (ctx->stage_big) (void)hipHostFree(ctx->stage_big);
     for (auto *h : ctx->hint_free) (void)hipHostFree(h);
+    if (ctx->ring_d) (void)hipFree(ctx->ring_d);
+    ctx->hint_plan.reset();
     if (ctx->pinned_base) (void)hipHostFree(ctx->pinned_base);
     if (ctx->recycle && ctx->bounce[0] && ctx->bounce[1] && ctx->device >= 0 && ctx->device < kMaxDevices) {
         RecycleBin &bin = g_recycle[ctx->device];
@@ -1979,25 +2013,30 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
             const uint32_t wv = (cw + 31) / 32, w1 = (cw / 2 + 31) / 32, w2 = (cw / 4 + 31) / 32;
             const size_t words = 2 * (size_t)wv + w1 + w2;
             if (words * 4 > kHintBytes) { rc = fail(ctx, ZIP_ERR_UNSUPPORTED, "hint bitmaps exceed their staging block"); break; }
-            if (!ctx->hint_free.empty()) {
-                c->hint_h = ctx->hint_free.back();
-                ctx->hint_free.pop_back();
-            } else if (hipHostMalloc((void **)&c->hint_h, kHintBytes, hipHostMallocDefault) != hipSuccess) {
-                c->hint_h = nullptr;
-                rc = fail(ctx, ZIP_ERR_ALLOC, "hipHostMalloc(%zu) failed", kHintBytes);
-                break;
-            }
             const bool direct = open_cols_d && commit_supports_direct(ctx, n_hint);
             const bool want_packed = !direct && c->compact_rows && n_hint && packed_enabled();
             c->plan = get_hint_plan(ctx, hint_cols, n_hint, want_packed);
-            uint32_t *bm = reinterpret_cast<uint32_t *>(c->hint_h);
-            memcpy(bm, c->plan->bm.data(), words * 4);
-            const uint32_t *nv = bm;
+            const bool resident = !direct && c->plan->dev;  // the tables already sit on the device (HintPlan::dev)
+            if (!resident) {  // per-commit staging block + upload: the direct mode's tables, or no device copy of the plan
+                if (!ctx->hint_free.empty()) {
+                    c->hint_h = ctx->hint_free.back();
+                    ctx->hint_free.pop_back();
+                } else if (hipHostMalloc((void **)&c->hint_h, kHintBytes, hipHostMallocDefault) != hipSuccess) {
+                    c->hint_h = nullptr;
+                    rc = fail(ctx, ZIP_ERR_ALLOC, "hipHostMalloc(%zu) failed", kHintBytes);
+                    break;
+                }
+            }
+            uint32_t *bm = resident ? nullptr : reinterpret_cast<uint32_t *>(c->hint_h);
+            if (bm) memcpy(bm, c->plan->bm.data(), words * 4);
+            const uint32_t *nv = c->plan->bm.data();
             c->hint_cols.assign(nv, nv + wv);
             size_t upload = words * 4;
             if (c->plan->packed) {
-                memcpy(c->hint_h + kHintTables, c->plan->wave_tab.data(), c->plan->wave_tab.size() * 4);
-                memcpy(c->hint_h + kPackedRanksAt, c->plan->own_ranks.data(), c->plan->own_ranks.size() * 2);
+                if (!resident) {
+                    memcpy(c->hint_h + kHintTables, c->plan->wave_tab.data(), c->plan->wave_tab.size() * 4);
+                    memcpy(c->hint_h + kPackedRanksAt, c->plan->own_ranks.data(), c->plan->own_ranks.size() * 2);
+                }
                 upload = kPackedRanksAt + c->plan->own_ranks.size() * 2;
                 c->packed = true;
                 c->pk_stride = c->plan->L.stride;
@@ -2021,10 +2060,16 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
                 for (uint32_t k = rank; k < n_hint; k++) firstr[k] = 0xFFFF;
                 upload = kHintTables + direct_table_bytes(cw, n_hint);
             }
-            if ((rc = pool_alloc(ctx, kHintBytes, (void **)&c->need_d))) break;
-            e = hipMemcpyAsync(c->need_d, bm, upload, hipMemcpyHostToDevice, ctx->s_commit);
-            if (e != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "hint upload failed: %s", hipGetErrorString(e)); break; }
-            a.need = c->need_d;
+            const unsigned char *tables_d;
+            if (resident) {
+                tables_d = c->plan->dev;
+            } else {
+                if ((rc = pool_alloc(ctx, kHintBytes, (void **)&c->need_d))) break;
+                e = hipMemcpyAsync(c->need_d, bm, upload, hipMemcpyHostToDevice, ctx->s_commit);
+                if (e != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "hint upload failed: %s", hipGetErrorString(e)); break; }
+                tables_d = reinterpret_cast<const unsigned char *>(c->need_d);
+            }
+            a.need = reinterpret_cast<const uint32_t *>(tables_d);
             c->hinted = true;
             if (c->packed) {
                 a.pk = reinterpret_cast<uint8_t *>(c->rows);
@@ -2032,8 +2077,8 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
                 a.pk_off0 = c->pk_off[0];
                 a.pk_off1 = c->pk_off[1];
                 a.pk_off2 = c->pk_off[2];
-                a.pk_tab = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(c->need_d) + kHintTables);
-                c->rank_d = reinterpret_cast<const uint16_t *>(reinterpret_cast<const unsigned char *>(c->need_d) + kPackedRanksAt);
+                a.pk_tab = reinterpret_cast<const uint32_t *>(tables_d + kHintTables);
+                c->rank_d = reinterpret_cast<const uint16_t *>(tables_d + kPackedRanksAt);
             }
             if (direct) {
                 const uint32_t rec = 8 + 32 * ctx->depth;
@@ -2052,10 +2097,34 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
             }
         }
         if (with_merkle && nch > 1) {
-            if ((rc = pool_alloc(ctx, (size_t)nch * 4, (void **)&c->chunk_done))) break;
-            e = hipMemsetAsync(c->chunk_done, 0, (size_t)nch * 4, ctx->s_commit);
-            c->zeroed = take_dep_event(ctx);
-            if (e == hipSuccess) e = hipEventRecord(c->zeroed, ctx->s_commit);
+            if (nch <= kRingStride && !ctx->ring_d) {  // first pipelined commit of this ctx
+                if (hipMalloc((void **)&ctx->ring_d, (size_t)kRingSlots * kRingStride * 4) != hipSuccess ||
+                    hipMemset(ctx->ring_d, 0, (size_t)kRingSlots * kRingStride * 4) != hipSuccess) {
+                    if (ctx->ring_d) (void)hipFree(ctx->ring_d);
+                    ctx->ring_d = nullptr;
+                    (void)hipGetLastError();
+                }
+            }
+            if (nch <= kRingStride && ctx->ring_d) {
+                if (ctx->ring_next == kRingSlots) {
+                    // every slot has been used: nobody may still poll one (the streams are idle between calls; a kept
+                    // handle notices the new epoch), then one memset for the next kRingSlots commits
+                    if (e == hipSuccess) e = stream_wait(ctx->stream);
+                    if (e == hipSuccess) e = stream_wait(ctx->s_commit);
+                    if (e == hipSuccess) e = hipMemsetAsync(ctx->ring_d, 0, (size_t)kRingSlots * kRingStride * 4, ctx->s_commit);
+                    if (e == hipSuccess) e = stream_wait(ctx->s_commit);
+                    ctx->ring_next = 0;
+                    ctx->ring_epoch++;
+                }
+                c->chunk_done = ctx->ring_d + (size_t)ctx->ring_next++ * kRingStride;
+                c->ring_slot = true;
+                c->ring_epoch = ctx->ring_epoch;
+            } else {
+                if ((rc = pool_alloc(ctx, (size_t)nch * 4, (void **)&c->chunk_done))) break;
+                e = hipMemsetAsync(c->chunk_done, 0, (size_t)nch * 4, ctx->s_commit);
+                c->zeroed = take_dep_event(ctx);
+                if (e == hipSuccess) e = hipEventRecord(c->zeroed, ctx->s_commit);
+            }
             a.chunk_done = c->chunk_done;
             c->expected.resize(nch);
             for (uint32_t k = 0; k < nch; k++) c->expected[k] = (R - c->bounds[k]) < G ? (R - c->bounds[k]) : G;
@@ -2154,7 +2223,7 @@ void zip_commitment_free(zip_commitment *c) {
     if (c->zeroed) c->ctx->dep_event_pool.push_back(c->zeroed);
     for (hipEvent_t e : c->aux) c->ctx->dep_event_pool.push_back(e);
     if (c->ctx->stream) (void)stream_wait(c->ctx->stream);
-    pool_release(c->ctx, c->chunk_done);
+    if (!c->ring_slot) pool_release(c->ctx, c->chunk_done);
     pool_release(c->ctx, c->need_d);
     if (c->hint_h) c->ctx->hint_free.push_back(c->hint_h);
     pool_release(c->ctx, c->rows);
