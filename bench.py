@@ -121,7 +121,7 @@ def pmc_entry(kernel, num_vars, mode):
         return None
 
 
-def commit_moved_bytes(per, row_len, cw, depth, cols, direct=False):
+def commit_moved_bytes(per, row_len, cw, depth, cols):
     """Bytes the commit kernel really moves per launch (as opposed to SURVEY 8d's full-materialisation figure): the
     witness, 16-byte row entries (the 96 significant bits + sign; Int<4> only on demand), the tree nodes, the
     children of levels >= 4 read back by the in-kernel upper levels, the roots.  cols = the opening hint (None: plain
@@ -136,8 +136,6 @@ def commit_moved_bytes(per, row_len, cw, depth, cols, direct=False):
         n1 = np.unique((c >> 1) ^ 1).size
         n2 = np.unique((c >> 2) ^ 1).size
         per_row = 16 * c.size + 32 * (n0 + n1 + n2 + upper_nodes)
-        if direct:  # zip_commit_open: value (32 B) + three siblings per OPENING, written into the proof
-            per_row = len(cols) * (32 + 3 * 32) + 32 * upper_nodes
     return int(per * (row_len * 8 + per_row + reread + 32))
 
 
@@ -386,12 +384,10 @@ def main():
         avg_ms = tot_ms / launches
         commit_bytes = per * row_len * 8 + per * cw * 32 * 3
         achieved = commit_bytes / (avg_ms * 1e-3) / 1e9
-        direct = (not args.no_hint and not args.two_calls and 512 <= cw <= 8192
-                  and os.environ.get("ZIP_HIP_DIRECT") == "1")  # commit_supports_direct (zip_hip.hip)
         # get_hint_plan (zip_hip.hip): every hinted commit of the 8- and 16-entries-per-thread kernels
-        packed = not args.no_hint and not direct and cw >= 512 and os.environ.get("ZIP_HIP_PACKED") != "0"
-        mode = "plain" if args.no_hint else "direct" if direct else "packed" if packed else "hinted"
-        moved = commit_moved_bytes(per, row_len, cw, depth, None if args.no_hint else cols, direct)
+        packed = not args.no_hint and cw >= 512 and os.environ.get("ZIP_HIP_PACKED") != "0"
+        mode = "plain" if args.no_hint else "packed" if packed else "hinted"
+        moved = commit_moved_bytes(per, row_len, cw, depth, None if args.no_hint else cols)
         pe = pmc_entry(dom, nv, mode) if not rows_mode else None
         traffic = int((2 * pe["fetch_kib"] + pe["write_kib"]) * 1024) if pe else None  # reads x2: profiles/*_fetch_calibration.md
         simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
@@ -429,9 +425,8 @@ def main():
                                      if packed else "") if args.two_calls else
                                   "zip_commit_open (one call, as commit_z_mle_and_prove_evaluation: the 1000 columns are "
                                   "known before the commit, prover.rs:316; stores no opening reads are skipped%s)"
-                                  % ("; ZIP_HIP_DIRECT=1: values and the three lowest siblings go straight into the proof"
-                                     if direct else "; what the openings read of the entries and of tree levels 0..2 is "
-                                     "stored packed, in index order" if packed else ""))},
+                                  % ("; what the openings read of the entries and of tree levels 0..2 is stored packed"
+                                     if packed else ""))},
             # the contract's HBM figure for the dominant kernel: SURVEY 8d algorithmic bytes / its launch time / 8 TB/s ...
             "roofline": {"bound": "valu", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -445,7 +440,7 @@ def main():
                                  "(16-byte row entries%s); `traffic` = FETCH_SIZE x2 + WRITE_SIZE of the committed PMC pass"
                                  % (per * (2 * cw - 1) / 1e6, "" if args.no_hint else ", only what the hinted openings read"
                                     + (", levels 0..2 and the entries packed" if packed else "")
-                                    + (", the values and three lowest siblings of every opening straight into the proof" if direct else ""))},
+                                    )},
             # ... and the roofline that does bind it
             "roofline_valu": valu,
             "roofline_gather": {"bound": "hbm", "kernel": "open_columns_kernel",

@@ -196,12 +196,7 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
  *   out        may be NULL (the handle is then freed); otherwise a handle like zip_commit_hinted's: anything later
  *              asked of it that is not in it first re-runs the commit in full, transparently -- a DEVICE `evals` must
  *              stay valid and unchanged until the handle is freed.
- * Unsharded ctx only.
- * ZIP_HIP_DIRECT=1 (environment, codeword_len 512..8192, at most 4096 openings) selects the variant in which the
- * commit kernel writes the opened column values and the three lowest siblings of every Merkle path straight from
- * its registers into the proof (30 % of the stream; read back from the trees each 32-byte node costs a 128-byte line
- * of HBM traffic, profiles/round2_fetch_calibration.md) and the gather only moves the rest: a third less HBM traffic,
- * the same bytes, about the same time on an otherwise idle GPU. */
+ * Unsharded ctx only. */
 int32_t zip_commit_open(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind, const int64_t *coeffs,
                         const uint32_t *cols, uint32_t n_cols, const uint64_t *q0_mont, const zip_field *field,
                         uint8_t *roots_out, uint8_t *proof_out, zip_mem_kind out_kind, zip_commitment **out);

@@ -81,19 +81,19 @@ def test_commit_open_2pow24(env):
     bad[proof.size // 2] ^= 1
     assert z.verify(f, roots, point, ev, bad, check_merkle=True) != 0
 
-    # zip_commit_open, both variants: the same 1.74 GiB, byte for byte (poisoned buffer first)
+    # zip_commit_open, packed openings and natural places: the same 1.74 GiB, byte for byte (poisoned buffer first)
     d_ref = torch.from_numpy(proof).cuda()
-    for direct in ("0", "1", "2"):
-        os.environ["ZIP_HIP_DIRECT"] = direct
+    for packed in ("1", "0"):
+        os.environ["ZIP_HIP_PACKED"] = packed
         try:
             d_one = torch.full((proof.size,), 0x33, dtype=torch.uint8, device="cuda")
             torch.cuda.synchronize()  # the fill runs on torch's stream, the library on its own
             _, roots_one, _ = ctx.commit_open(d_evals, coeffs, cols, q0, cabi.make_field(BENCH_MODULUS, 4), out=d_one)
             ctx.synchronize()
         finally:
-            os.environ.pop("ZIP_HIP_DIRECT", None)
+            os.environ.pop("ZIP_HIP_PACKED", None)
         assert np.array_equal(roots_one, roots)
-        assert torch.equal(d_one, d_ref), direct
+        assert torch.equal(d_one, d_ref), packed
         del d_one
     del d_ref
 
@@ -229,11 +229,11 @@ def test_commit_open_2pow26_full_on_one_gpu(env):
     com2.free()
 
 
-@pytest.mark.parametrize("hinted", [False, True, "one_call", "one_call_direct", "one_call_direct_last"])
+@pytest.mark.parametrize("hinted", [False, True, "unpacked", "one_call", "one_call_unpacked"])
 def test_commit_open_2pow22_pipelined_gather_byte_diff(env, hinted, monkeypatch):
     """2^22 with the default chunking (two chunks: the gather of the first runs beside the hashing of the second):
-    sampled proof blocks byte for byte against oracle-built rows and paths -- plain commit, hinted commit, and
-    zip_commit_open (low part of every opening written by the commit kernel)."""
+    sampled proof blocks byte for byte against oracle-built rows and paths -- plain commit, hinted commit (packed
+    openings, and the natural places with ZIP_HIP_PACKED=0) and zip_commit_open (the same two)."""
     cabi, torch = env
     nv = 22
     z = orc.Zip(nv)
@@ -245,8 +245,8 @@ def test_commit_open_2pow22_pipelined_gather_byte_diff(env, hinted, monkeypatch)
     d_evals = torch.from_numpy(evals).cuda()
     proof = torch.full((ctx.proof_len(1000, 4),), 0x55, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()  # the fill runs on torch's stream, the library on its own
-    monkeypatch.setenv("ZIP_HIP_DIRECT", {"one_call_direct": "1", "one_call_direct_last": "2"}.get(hinted, "0"))
-    if hinted in ("one_call", "one_call_direct", "one_call_direct_last"):
+    monkeypatch.setenv("ZIP_HIP_PACKED", "0" if hinted in ("unpacked", "one_call_unpacked") else "1")
+    if hinted in ("one_call", "one_call_unpacked"):
         _, _, com = ctx.commit_open(d_evals, coeffs, cols, q0, zf, out=proof, want_roots=False, keep=True)
     else:
         com, _ = ctx.commit(d_evals, want_roots=False, hint_cols=cols if hinted else None)  # asynchronous

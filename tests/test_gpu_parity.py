@@ -407,19 +407,14 @@ def test_hinted_commit_opens_bit_exact_and_completes_itself(cabi, geometry):
 
 @pytest.mark.parametrize("geometry", [(16, None), (17, None), (18, None), (20, None), (17, (8192, 16, 16384)), (12, None), (9, None)])
 @pytest.mark.parametrize("device_out", [False, True])
-@pytest.mark.parametrize("direct", ["0", "unpacked", "1", "2"])
-def test_commit_open_in_one_call_is_byte_identical(cabi, geometry, device_out, direct, monkeypatch):
-    """zip_commit_open (the binding for commit_z_mle_and_prove_evaluation, prover.rs:305-328).  Default ("0"): what the
-    openings read of the row entries and of tree levels 0..2 is stored packed, in index order, and gathered from there
-    (codeword >= 512; the repeated columns of codeword 512, neighbours that are each other's sibling, nodes that serve
-    four columns all go through the rank tables).  "unpacked" (ZIP_HIP_PACKED=0): the same stores at their natural
-    places.  ZIP_HIP_DIRECT=1: the
-    commit kernel itself writes the opened values and the three lowest siblings of every path into the proof -- at EVERY
-    place the wire format wants them (at codeword 512 the 1000 squeezed columns repeat, and a level-2 node serves up to
-    four columns) -- and the gather behind it the rest.  Roots and every proof byte equal the oracle's; the output
-    buffer is poisoned first, so a byte nobody wrote shows.  (codeword 128 / 16384: no direct variant, same result.)"""
-    monkeypatch.setenv("ZIP_HIP_DIRECT", "0" if direct == "unpacked" else direct)
-    monkeypatch.setenv("ZIP_HIP_PACKED", "0" if direct == "unpacked" else "1")
+@pytest.mark.parametrize("packed", ["1", "0"])
+def test_commit_open_in_one_call_is_byte_identical(cabi, geometry, device_out, packed, monkeypatch):
+    """zip_commit_open (the binding for commit_z_mle_and_prove_evaluation, prover.rs:305-328).  Default: what the
+    openings read of the row entries and of tree levels 0..2 is stored packed and gathered from there (codeword >= 512,
+    both commit kernels; the repeated columns of codeword 512, neighbours that are each other's sibling, nodes that
+    serve four columns all go through the rank tables).  ZIP_HIP_PACKED=0: the same stores at their natural places.
+    Roots and every proof byte equal the oracle's; the output buffer is poisoned first, so a byte nobody wrote shows."""
+    monkeypatch.setenv("ZIP_HIP_PACKED", packed)
     nv, geo = geometry
     z = orc.Zip(nv, geometry=geo) if geo else orc.Zip(nv)
     f = orc.make_field(BENCH_MODULUS, 4)

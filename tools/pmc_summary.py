@@ -52,8 +52,8 @@ def classify(kernel):
             return None
         if "raa_commit16" in k:  # <T, HASH, MASKED>
             mode = "hinted" if (len(args) > 2 and args[2] == "true") else "plain"
-        else:  # <E, HASH, MODE>: 0 everything stored, 1 hinted, 2 direct, 3 packed (zip_commit_open)
-            mode = {"0": "plain", "1": "hinted", "2": "direct", "3": "packed"}.get(args[2] if len(args) > 2 else "0", "plain")
+        else:  # <E, HASH, MODE>: 0 everything stored, 1 hinted at the natural places, 3 hinted and packed
+            mode = {"0": "plain", "1": "hinted", "3": "packed"}.get(args[2] if len(args) > 2 else "0", "plain")
         return "raa_commit_kernel", mode
     if "open_columns_kernel" in k:
         return "open_columns_kernel", "any"

@@ -54,27 +54,6 @@ struct CommitArgs {
     // its end into clock[0..3] -- the shader clock the chip actually held during THIS launch (the VALU roofline
     // of bench.py is priced at that clock, not at a datasheet figure)
     unsigned long long *clock;
-    // Direct openings (zip_commit_open, MODE 2): the proof of the hinted columns is being written in the same call, so
-    // the entries and the level-0..2 siblings an opening reads go STRAIGHT into the proof stream (at every place the
-    // wire format wants them: a column may be opened more than once, a level-l node is the sibling of up to 2^l
-    // columns) instead of into rows / layers, where the gather would pay a 128-byte line of HBM reads for each
-    // 32-byte node (profiles/round2_fetch_calibration.md).  open_cols = start of the column openings in the
-    // proof; column opening i: num_rows values of 32 B, then num_rows records of rec_bytes (pcs_transcript.rs:198-211).
-    // Column -> openings lists (global memory; every workgroup turns them once into per-lane destination lists in
-    // LDS, 8 bytes per opening):
-    //   vp[cw / 32]      bits 0..31: which of the 32 columns of the word are opened; bits 32..: how many opened columns
-    //                    precede the word (so rank(c) = that + popcount of the lower bits)
-    //   firstr[rank]     first index i with cols[i] == that column, u16
-    //   next[i]          next index with the same column (0xFFFF: none), u16
-    uint8_t *open_cols;
-    uint64_t per_col;         // bytes of one column opening = rows_total * (32 + rec_bytes)
-    uint32_t rec_bytes;       // 8 + 32 * depth
-    uint32_t rows_total;      // num_rows of the polynomial (this launch covers all of them)
-    uint32_t n_open;          // number of openings (length of next[]; firstr[] is padded to the same length)
-    const uint64_t *open_tab;  // device: vp[cw / 32] | firstr[n_open] | next[n_open]; copied into LDS by every workgroup
-    uint32_t direct_from_row;  // MODE 2: rows below this one are stored as in MODE 1 (into rows / layers); the direct
-                               // stores then only serve the rows whose gather ends the step (the last chunk)
-    uint32_t exp_flags;        // TIMING EXPERIMENTS ONLY (ZIP_HIP_EXP_DIRECT): 1 = look up, do not store
 #ifdef ZIPK_DEBUG_STAMPS
     unsigned long long *stamps;  // tools/ubench_pipeline.hip: [chunk][workgroup] wall-clock of each arrival
 #endif
@@ -183,23 +162,13 @@ __device__ __forceinline__ void subtree_hash(Src &src, uint32_t (&h)[8]) {
 // butterfly: at level l a lane exchanges one child hash with lane t ^ 2^(l-1) and ends up
 // with the node of step E0 + (t mod 2^l).  Every lane still hashes E leaves, E/2 ... 1 nodes.
 // MODE 0: every entry and node is stored.  MODE 1 (zip_commit_hinted): stores no opening of the hinted columns reads
-// are predicated off.  MODE 2 (zip_commit_open, opt-in): as 1, and what the openings read of the entries and of levels
-// 0..2 is written into the proof stream itself (CommitArgs.open_cols) instead of into rows / layers.  MODE 3
-// (zip_commit_open): as 1, but those stores go to the packed per-row block (CommitArgs.pk).  A lane's place in a
+// are predicated off, at the natural places (ZIP_HIP_PACKED=0, and what hinted commits below codeword 512 ... do not
+// have: they store everything).  MODE 3 (hinted commits): as 1, but what the openings read of the entries and of
+// levels 0..2 goes to the packed per-row block (CommitArgs.pk).  A lane's place in a
 // section is the rank of its entry / node among the section's members: the members owned by the lanes of one wave at
 // one store site are consecutive in index order (per parity class for level 1, per tid mod 4 for level 2), so the
 // rank is a per-wave base (pk_tab, row invariant, held in scalar registers) + the number of storing lanes below.
-constexpr int kStoreAll = 0, kStoreHinted = 1, kStoreDirect = 2, kStorePacked = 3;
-
-// 32 bytes to an address that is only 8-byte aligned (a path record starts 8 bytes past a multiple of 32): two
-// global_store_dwordx4 -- the hardware wants dword alignment for them, not 16 bytes -- because what these scattered
-// stores cost is one memory-pipeline transaction per lane and instruction, and four 8-byte stores are twice as many.
-struct __attribute__((packed, aligned(8))) u128_a8 { uint32_t x, y, z, w; };
-__device__ __forceinline__ void store_hash8(uint8_t *dst, const uint32_t (&h)[8]) {
-    u128_a8 *d = reinterpret_cast<u128_a8 *>(dst);
-    d[0] = u128_a8{h[0], h[1], h[2], h[3]};
-    d[1] = u128_a8{h[4], h[5], h[6], h[7]};
-}
+constexpr int kStoreAll = 0, kStoreHinted = 1, kStorePacked = 3;
 
 template <int E, int MODE = kStoreAll>
 struct StridedLeaves {
@@ -214,16 +183,6 @@ struct StridedLeaves {
     // (row invariant, see store_mask below): bit e = row entry of step e, bit 8 + e = its leaf hash, bits 16.. =
     // the lane's level-1 nodes (E0 / 2), bits 24.. = its level-2 nodes (E0 / 4).
     uint32_t smask = 0xFFFFFFFFu;
-    // MODE 2: this row's slots in opening 0 (values: 32-byte aligned; records: + 8 past the length prefix, 8-byte
-    // aligned), the stride between openings and the column -> openings lists (LDS)
-    uint8_t *pvals = nullptr, *precs = nullptr;
-    uint32_t per_col8 = 0;  // bytes of one column opening / 8 (< 2^24: full-rate 24-bit multiply; offsets stay below 2^32)
-    // the lane's destination list (LDS, built once per kernel by build_dest_list): for every store site that has its
-    // mask bit set, in the order the butterfly visits them, the opening indices it goes to; bit 15 = one more follows
-    const uint16_t *dlist = nullptr;
-    uint32_t cur = 0;
-    uint32_t exp_flags = 0;
-    bool direct = false;  // MODE 2, this row (wave-uniform): into the proof; else as MODE 1
     // MODE 3: this row's packed block, the section offsets and the wave's 32 base ranks (two per word)
     uint8_t *pk_row = nullptr;
     uint32_t pk_off0 = 0, pk_off1 = 0, pk_off2 = 0;
@@ -234,28 +193,12 @@ struct StridedLeaves {
     static __device__ __forceinline__ uint32_t lanes_below(uint64_t m) {
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     }
-    template <class F>
-    __device__ __forceinline__ void for_dests(F f) {
-        uint32_t e;
-        do {
-            e = dlist[cur++];
-            f(e & 0x7FFFu);
-        } while (e & 0x8000u);
-    }
-
     template <int E0>
     __device__ __forceinline__ void store_row() {
         if (MASKED && !(smask & (1u << E0))) return;
         const uint32_t j = base + E0 * T + tid;
         const uint32_t s = (uint32_t)((int32_t)w2[E0] >> 31);
-        if (MODE == kStoreDirect && direct) {  // rows[r * cw + j] as K little-endian limbs into every opening of column j
-            for_dests([&](uint32_t i) {
-                uint4 *o = reinterpret_cast<uint4 *>(pvals + ((size_t)__umul24(i, per_col8) << 3));
-                if (exp_flags & 1u) { if (i == 0x7FFEu) o[0] = make_uint4(s, s, s, s); return; }
-                o[0] = make_uint4(w0[E0], w1[E0], w2[E0], s);
-                o[1] = make_uint4(s, s, s, s);
-            });
-        } else if (MODE == kStorePacked) {
+        if (MODE == kStorePacked) {
             const uint32_t pos = pbase<E0>() + lanes_below(__builtin_amdgcn_ballot_w64(true));
             *reinterpret_cast<uint4 *>(pk_row + (size_t)pos * 16) = make_uint4(w0[E0], w1[E0], w2[E0], s);
         } else if (compact) {
@@ -266,22 +209,12 @@ struct StridedLeaves {
             o[1] = make_uint4(s, s, s, s);
         }
     }
-    // MODE 2: a level-LVL node is the level-LVL sibling on the path of every opened column below its sibling node
-    template <int LVL>
-    __device__ __forceinline__ void store_sibling(const uint32_t (&h)[8]) {
-        for_dests([&](uint32_t i) {
-            if ((exp_flags & 1u) && i != 0x7FFEu) return;
-            store_hash8(precs + ((size_t)(__umul24(i, per_col8) + 4u * LVL) << 3), h);
-        });
-    }
     template <int E0>
     __device__ __forceinline__ void leaf(uint32_t (&h)[8]) {
         store_row<E0>();
         blake3_leaf_sext96(w0[E0], w1[E0], w2[E0], h);
         if (!MASKED || (smask & (0x100u << E0))) {
-            if (MODE == kStoreDirect && direct) {
-                store_sibling<0>(h);
-            } else if (MODE == kStorePacked) {
+            if (MODE == kStorePacked) {
                 const uint32_t pos = pbase<8 + E0>() + lanes_below(__builtin_amdgcn_ballot_w64(true));
                 store_hash(reinterpret_cast<uint32_t *>(pk_row + pk_off0) + (size_t)pos * 8, h);
             } else {
@@ -295,9 +228,7 @@ struct StridedLeaves {
         if (MASKED && LVL <= 2 && !(smask & ((LVL == 1 ? 0x10000u : 0x1000000u) << (E0 >> LVL)))) return;
         const uint32_t e = E0 + (tid & ((1u << LVL) - 1u));
         const uint32_t n = (base + e * T + tid) >> LVL;
-        if (MODE == kStoreDirect && direct && LVL <= 2) {
-            store_sibling<LVL>(h);
-        } else if (MODE == kStorePacked && LVL == 1) {  // even lanes own the first half of the group's nodes, odd the second
+        if (MODE == kStorePacked && LVL == 1) {  // even lanes own the first half of the group's nodes, odd the second
             const uint64_t act = __builtin_amdgcn_ballot_w64(true);
             const bool odd = tid & 1u;
             const uint32_t pos = (odd ? pbase<16 + (E0 >> 1) * 2 + 1>() : pbase<16 + (E0 >> 1) * 2>()) +
@@ -342,48 +273,6 @@ __device__ __forceinline__ uint32_t store_mask(const uint32_t *need, uint32_t cw
     }
     return m;
 }
-
-// ---- zip_commit_open: the per-lane destination lists ------------------------------------------------------------
-// Store sites of one lane in the order bfly_hash visits them: value and leaf hash of step E0, then (after both
-// halves) the node of level LVL.  W gets the column range whose openings the site's value / hash goes to.
-template <int LVL, int E0, class W>
-__device__ __forceinline__ void walk_sites(W &w) {
-    if constexpr (LVL == 0) {
-        w.site(w.entry(E0), 1u);        // the entry itself: every opening of its column
-        w.site(w.entry(E0) ^ 1u, 1u);   // its leaf hash: level-0 sibling of the neighbour column
-    } else {
-        walk_sites<LVL - 1, E0>(w);
-        walk_sites<LVL - 1, E0 + (1 << (LVL - 1))>(w);
-        if (LVL <= 2) {
-            const uint32_t n = w.entry(E0 + (w.tid & ((1u << LVL) - 1u))) >> LVL;
-            w.site((n ^ 1u) << LVL, 1u << LVL);  // level-LVL sibling of every column below node n ^ 1
-        }
-    }
-}
-// Walks the openings of the columns [c0, c0 + n) through the global tables of CommitArgs.open_tab.  FILL = false
-// counts them; FILL = true appends them to the lane's list (bit 15 on all but the last of a site).
-template <bool FILL>
-struct DestWalker {
-    const uint64_t *vp;
-    const uint16_t *firstr, *next;
-    uint16_t *dlist;
-    uint32_t T, tid, count;
-    __device__ __forceinline__ uint32_t entry(uint32_t e) const { return e * T + tid; }
-    __device__ __forceinline__ void site(uint32_t c0, uint32_t n) {
-        const uint32_t begin = count;
-        for (uint32_t c = c0; c < c0 + n; c++) {
-            const uint64_t w = vp[c >> 5];
-            const uint32_t bits = (uint32_t)w;
-            if (!((bits >> (c & 31u)) & 1u)) continue;
-            const uint32_t rank = (uint32_t)(w >> 32) + __builtin_popcount(bits & ((1u << (c & 31u)) - 1u));
-            for (uint32_t i = firstr[rank]; i != 0xFFFFu; i = next[i]) {
-                if (FILL) dlist[count] = (uint16_t)(i | 0x8000u);
-                count++;
-            }
-        }
-        if (FILL && count > begin) dlist[count - 1] &= 0x7FFFu;
-    }
-};
 
 template <int E, int E0, class Src>
 __device__ __forceinline__ void store_rows_only(Src &src) {
@@ -580,19 +469,6 @@ __global__ void __launch_bounds__(1024, MODE != kStoreAll ? 4 : 5) raa_commit_ke
     int64_t *rowbuf = reinterpret_cast<int64_t *>(t2hi + E * PS);
     // the t2 planes are dead while a chunk is finished: ping-pong space for the upper tree levels
     const UpperScratch us{reinterpret_cast<uint32_t *>(t2lo), t2hi, (uint32_t)(E * PS * 8 / 32), (uint32_t)(E * PS * 4 / 32)};
-    // MODE 2: the lanes' destination lists (4 per opening: its value and three siblings), built once from the global
-    // tables; every lane only ever reads its own stretch, beginning at dcur0
-    uint16_t *dlist = reinterpret_cast<uint16_t *>(rowbuf + row_len);
-    uint32_t dcur0 = 0;
-    if (MODE == kStoreDirect) {
-        const uint16_t *firstr = reinterpret_cast<const uint16_t *>(a.open_tab + cw / 32);
-        DestWalker<false> cnt{a.open_tab, firstr, firstr + a.n_open, dlist, a.nact, tid0, 0u};
-        if (active) walk_sites<LOGE, 0>(cnt);
-        dcur0 = (uint32_t)(uint64_t)block_exclusive_scan_i96((i128)cnt.count, wave_tot, 1);
-        DestWalker<true> fill{a.open_tab, firstr, firstr + a.n_open, dlist, a.nact, tid0, dcur0};
-        if (active) walk_sites<LOGE, 0>(fill);
-    }
-
     // Row-invariant state kept in registers so that no global load sits on the per-row critical
     // path: the thread's permutation indices (packed: pi1 source index | pi2 LDS slot << 16) ...
     uint32_t pidx[E];
@@ -720,15 +596,6 @@ __global__ void __launch_bounds__(1024, MODE != kStoreAll ? 4 : 5) raa_commit_ke
             src.T = a.nact;
             src.tid = tid;
             src.smask = smask;
-            if (MODE == kStoreDirect) {
-                src.pvals = a.open_cols + (size_t)row * 32u;
-                src.precs = a.open_cols + (size_t)a.rows_total * 32u + (size_t)row * a.rec_bytes + 8u;
-                src.per_col8 = (uint32_t)(a.per_col >> 3);
-                src.dlist = dlist;
-                src.cur = dcur0;
-                src.exp_flags = a.exp_flags;
-                src.direct = row >= a.direct_from_row;
-            }
             if (MODE == kStorePacked) {
                 src.pk_row = a.pk + (size_t)row * a.pk_stride;
                 src.pk_off0 = a.pk_off0;
@@ -825,7 +692,7 @@ __device__ __forceinline__ void transpose8(uint32_t (&x)[8], uint32_t lane) {
 template <uint32_t T, bool HASH, int MODE = kStoreAll>
 __global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
     constexpr bool MASKED = MODE != kStoreAll;
-    static_assert(MODE == kStoreAll || MODE == kStoreHinted || MODE == kStorePacked, "no direct variant");
+    static_assert(MODE == kStoreAll || MODE == kStoreHinted || MODE == kStorePacked, "store mode");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int E = 16;
     constexpr uint32_t PS = T + 2;  // plane stride of the 16 t2 planes

@@ -380,9 +380,6 @@ struct OpenColsArgs {
     const uint8_t *pk;
     uint32_t pk_stride, pk_off0, pk_off1, pk_off2;
     const uint16_t *pk_rank;  // [n_cols][4] (device)
-    uint32_t skip_low;        // zip_commit_open: the column values and the siblings of the levels below this one are
-                              // already in the proof (written by the commit kernel, CommitArgs.open_cols): neither
-                              // read nor written here.  0: the whole opening.
 };
 
 // Grid (n_cols, row blocks): blocks that run together share a narrow band of rows, so the
@@ -417,9 +414,6 @@ __global__ void __launch_bounds__(256) open_columns_kernel(OpenColsArgs a) {
     // ---- phase 1: gather sibling hashes into the LDS image ----
     // lane role h < 2*depth: half (h & 1) of the level-(h >> 1) sibling (pcs/utils.rs:163-176);
     // h == 2*depth: the be64(depth) length prefix (pcs_transcript.rs:200-203).
-    // skip_low: the image only holds what this kernel writes -- per record the length prefix and the siblings from
-    // level skip_low up, packed (img_rec bytes).
-    const uint32_t img_rec = rec_bytes - 32 * a.skip_low;
     {
         const uint32_t h = threadIdx.x & (SLOTS - 1), rsub = threadIdx.x / SLOTS;
         const uint32_t lvl = h >> 1;
@@ -432,9 +426,9 @@ __global__ void __launch_bounds__(256) open_columns_kernel(OpenColsArgs a) {
                                                      (size_t)a.pk_rank[ci * 4 + 1 + lvl] * 32) + (h & 1) * 2;
             src_step = (size_t)RPP * (a.pk_stride / 8);
         }
-        unsigned char *dst = img + (size_t)rsub * img_rec + 8 + (size_t)(h - 2 * a.skip_low) * 16;
-        const uint32_t dst_step = RPP * img_rec;
-        if (h < 2 * d && lvl >= a.skip_low) {
+        unsigned char *dst = img + (size_t)rsub * rec_bytes + 8 + (size_t)h * 16;
+        const uint32_t dst_step = RPP * rec_bytes;
+        if (h < 2 * d) {
 #pragma unroll 4
             for (uint32_t rr = rsub; rr < nrows; rr += RPP, src += src_step, dst += dst_step) {
                 const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src);
@@ -444,13 +438,13 @@ __global__ void __launch_bounds__(256) open_columns_kernel(OpenColsArgs a) {
         } else if (h == 2 * d) {
             const uint64_t hdr = __builtin_bswap64((uint64_t)d);
             for (uint32_t rr = rsub; rr < nrows; rr += RPP)
-                *reinterpret_cast<uint64_t *>(img + (size_t)rr * img_rec) = hdr;
+                *reinterpret_cast<uint64_t *>(img + (size_t)rr * rec_bytes) = hdr;
         }
     }
     // ---- column values: rows[r*cw + col], K limbs little-endian (open_z.rs:130-137) ----
     {
         const uint32_t half = threadIdx.x & 1, rsub = threadIdx.x >> 1;  // two 16-byte halves per value
-        if (rsub < nrows && !a.skip_low) {
+        if (rsub < nrows) {
             const uint32_t r = r0 + rsub;
             ulonglong2 v;
             if (a.compact_rows) {  // (w0, w1, w2, sign): the upper half of the Int<4> is the sign word four times
@@ -469,45 +463,7 @@ __global__ void __launch_bounds__(256) open_columns_kernel(OpenColsArgs a) {
     // ---- phase 2: stream the image out ----
     unsigned char *recs = base + (size_t)a.num_rows * 8 * K + (size_t)r0 * rec_bytes;
     const uint32_t total = nrows * rec_bytes;
-    if (a.skip_low == 3 && (reinterpret_cast<uintptr_t>(recs) & 15) == 0 && d > 3) {
-        // Bytes [8, 104) of every record (the siblings of levels 0..2) belong to the commit kernel.  What is left of a
-        // PAIR of records (r even, so r * rec_bytes is a multiple of 16) is two 16-byte-aligned runs,
-        //   [r * rec + 112, (r + 1) * rec + 8)   and   [(r + 1) * rec + 104, (r + 2) * rec)
-        // of nb = 2 (depth - 3) 16-byte pieces each, plus the 8-byte length prefix of record r and the 8 bytes at
-        // r * rec + 104: 2 nb + 2 lanes per pair, 16-byte stores for all but two of them.  In the packed image the
-        // same pieces sit at r * img_rec + 16, (r + 1) * img_rec + 8, r * img_rec and r * img_rec + 8.
-        const uint32_t nb = 2 * (d - 3), lanes = 2 * nb + 2, per_pass = 256 / lanes, npairs = (nrows + 1) / 2;
-        const uint32_t slot = threadIdx.x / lanes, k = threadIdx.x - slot * lanes;
-        if (slot < per_pass) {
-            for (uint32_t p = slot; p < npairs; p += per_pass) {
-                const uint32_t r = 2 * p, off0 = r * rec_bytes, im0 = r * img_rec;
-                const bool has_next = r + 1 < nrows;
-                if (k < nb) {
-                    const uint32_t off = off0 + 112 + 16 * k, im = im0 + 16 + 16 * k;
-                    if (k + 1 < nb || has_next)
-                        *reinterpret_cast<uint4 *>(recs + off) = *reinterpret_cast<const uint4 *>(img + im);
-                    else  // last record of the block: the run ends with the record, not with the next length prefix
-                        *reinterpret_cast<uint64_t *>(recs + off) = *reinterpret_cast<const uint64_t *>(img + im);
-                } else if (k < 2 * nb) {
-                    if (has_next) {
-                        const uint32_t off = off0 + rec_bytes + 104 + 16 * (k - nb), im = im0 + img_rec + 8 + 16 * (k - nb);
-                        *reinterpret_cast<uint4 *>(recs + off) = *reinterpret_cast<const uint4 *>(img + im);
-                    }
-                } else {
-                    const uint32_t off = off0 + (k == 2 * nb ? 0u : 104u), im = im0 + (k == 2 * nb ? 0u : 8u);
-                    *reinterpret_cast<uint64_t *>(recs + off) = *reinterpret_cast<const uint64_t *>(img + im);
-                }
-            }
-        }
-    } else if (a.skip_low) {
-        // the same as 8-byte words: word 0 and words [lo, rec_words) of every record <- packed words [0, keep)
-        const uint32_t rec_words = rec_bytes / 8, lo = 1 + 4 * a.skip_low, keep = rec_words - (lo - 1);
-        for (uint32_t idx = threadIdx.x; idx < nrows * keep; idx += 256) {
-            const uint32_t rec = idx / keep, k = idx - rec * keep;
-            reinterpret_cast<uint64_t *>(recs)[rec * rec_words + (k ? k + lo - 1 : 0u)] =
-                reinterpret_cast<const uint64_t *>(img)[rec * keep + k];
-        }
-    } else if ((reinterpret_cast<uintptr_t>(recs) & 15) == 0) {
+    if ((reinterpret_cast<uintptr_t>(recs) & 15) == 0) {
         const uint32_t n16 = total / 16;
         for (uint32_t i = threadIdx.x; i < n16; i += 256)
             reinterpret_cast<uint4 *>(recs)[i] = reinterpret_cast<const uint4 *>(img)[i];
@@ -519,7 +475,7 @@ __global__ void __launch_bounds__(256) open_columns_kernel(OpenColsArgs a) {
     }
 }
 
-// The same openings without the LDS image (skip_low == 0): every lane moves 16 bytes per row straight from where they
+// The same openings without the LDS image: every lane moves 16 bytes per row straight from where they
 // are to where the wire format wants them.  The siblings of a record sit at 8 (mod 16) in every other record, so the
 // stores are 16-byte stores to 8-byte-aligned addresses (global_store_dwordx4 only wants dword alignment); the lanes
 // of a row still write one contiguous run.  Roles of the SLOTS lanes reserved per row:

@@ -161,8 +161,6 @@ struct zip_commitment {
     // set (bit c = column c was hinted); anything else asked of the handle first re-runs the commit in full
     // (rematerialize) from the witness: `evals` above, or the caller's device array `evals_ref`.
     bool hinted = false;
-    bool direct = false;  // zip_commit_open: values and level-0..2 siblings went into the proof, not into rows / layers ...
-    uint32_t direct_from_row = 0;  // ... for the rows from this one on
     // zip_commit_open, packed openings: values and level-0..2 nodes of the hinted columns sit densely in `rows`
     // (CommitArgs.pk), at the positions `plan` holds
     bool packed = false;
@@ -759,16 +757,11 @@ int32_t ensure_dynamic_lds(zip_ctx *ctx, const void *kern, size_t bytes) {
 }
 
 // ------------------------------------------------------------------ commit dispatch
-// LDS of the per-lane destination lists of the direct commit kernel: four u16 entries per opening
-size_t direct_lds_bytes(uint32_t n_cols) { return ((size_t)n_cols * 8 + 15) & ~(size_t)15; }
-// bytes of CommitArgs.open_tab: vp[cw / 32] (u64) | firstr[n_cols] | next[n_cols] (u16), rounded to 16
-size_t direct_table_bytes(uint32_t cw, uint32_t n_cols) { return ((size_t)cw / 32 * 8 + (size_t)n_cols * 4 + 15) & ~(size_t)15; }
 // Persistent launch: as many workgroups as stay resident together (at most one per row).
 template <int E, bool HASH, int MODE = kStoreAll>
 int32_t launch_commit(zip_ctx *ctx, const CommitArgs &a, uint32_t threads, uint32_t grid, hipStream_t st) {
     // wave totals + E planes of (threads + 32/E) slots of 12 bytes + the witness row (+ the opening tables)
     size_t lds = 512 + (size_t)E * (threads + 32 / E) * 12 + (size_t)a.row_len * 8;
-    if (MODE == kStoreDirect) lds += direct_lds_bytes(a.n_open);
     auto kern = raa_commit_kernel<E, HASH, MODE>;
     if (int32_t rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
     LaunchTimer t(ctx, HASH ? "raa_commit_kernel" : "raa_encode_kernel", st);
@@ -827,26 +820,6 @@ bool commit_supports_hint(uint32_t cw) { return cw >= 512; }
 // (packed openings: the wave table at kHintTables, the ranks of the hinted openings at kPackedRanksAt)
 constexpr uint32_t kRingSlots = 64, kRingStride = 8;  // zip_ctx::ring_d
 constexpr size_t kHintTables = 8192, kHintBytes = kHintTables + 8 * (8192 / 32) + 4 * 4096 + 64, kPackedRanksAt = kHintTables + 2048;
-constexpr uint32_t kDirectMaxCols = 4096;
-// zip_commit_open writes the low part of the openings from the commit kernel where that kernel has the variant
-// (8 entries per thread) and room in LDS for the tables; elsewhere it is zip_commit_hinted + the whole gather
-bool commit_supports_direct(const zip_ctx *ctx, uint32_t n_cols) {
-    const uint32_t cw = ctx->p.codeword_len;
-    // Opt-in (ZIP_HIP_DIRECT=1).  Measured at 2^24: the gather's time falls from 1.25-1.45 to 0.9 ms per step and its
-    // HBM traffic by a third, but the commit kernel pays 0.15 ms for the scattered stores (one memory-pipeline pass
-    // per store instruction whatever the number of active lanes) and is the critical path: 2.05-2.09 ms per step
-    // against 2.00-2.10 for zip_commit_hinted + the whole gather.  Kept for streams that are HBM-bound beside it.
-    { const char *e = getenv("ZIP_HIP_DIRECT"); if (!e || (atoi(e) != 1 && atoi(e) != 2)) return false; }
-    if (ctx->rows_local != ctx->p.num_rows || n_cols == 0 || n_cols > kDirectMaxCols) return false;
-    if (cw < 512 || cw > 8192 || ctx->depth < 3) return false;
-    const CommitGeom g = commit_geom(cw, ctx->p.row_len);
-    if (g.e != 8) return false;
-    // (24-bit multiply and 32-bit offsets in the kernel's store addresses)
-    const uint64_t per_col = (uint64_t)ctx->p.num_rows * (32 + 8 + 32 * (uint64_t)ctx->depth);
-    if ((per_col >> 3) >= (1u << 24) || per_col * n_cols >= ((uint64_t)1 << 35)) return false;
-    return g.lds + direct_lds_bytes(n_cols) + 64 <= 160u * 1024u;
-}
-
 // ---- opening hints and packed openings (CommitArgs.need / .pk) -------------------------------------------------
 // Everything a hinted commit derives from its column list, kept per ctx until the list changes (in the prover flow it
 // never does: a fresh PcsTranscript squeezes the same columns for every proof, zinc/prover.rs:316).
@@ -966,8 +939,6 @@ int32_t dispatch_commit(zip_ctx *ctx, CommitArgs a, uint32_t grid, hipStream_t s
     const CommitGeom g = commit_geom(a.cw, a.row_len);
     a.nact = a.cw / g.e < g.threads ? a.cw / g.e : g.threads;
     if (HASH && a.need) {  // opening hint: only the two big geometries have a masked variant (commit_supports_hint)
-        if (g.e == 8 && a.open_cols) return launch_commit<8, HASH, HASH ? kStoreDirect : kStoreAll>(ctx, a, g.threads, grid, st);
-        a.open_cols = nullptr;
         if (g.e == 8 && a.pk) return launch_commit<8, HASH, HASH ? kStorePacked : kStoreAll>(ctx, a, g.threads, grid, st);
         if (g.e == 16 && a.pk) return launch_commit16<HASH, HASH ? kStorePacked : kStoreAll>(ctx, a, grid, st);
         a.pk = nullptr;
@@ -975,7 +946,6 @@ int32_t dispatch_commit(zip_ctx *ctx, CommitArgs a, uint32_t grid, hipStream_t s
         if (g.e == 8) return launch_commit<8, HASH, HASH ? kStoreHinted : kStoreAll>(ctx, a, g.threads, grid, st);
         a.need = nullptr;
     }
-    a.open_cols = nullptr;
     a.pk = nullptr;
     switch (g.e) {
         case 16: return launch_commit16<HASH>(ctx, a, grid, st);
@@ -1185,7 +1155,7 @@ void gather_order(const uint32_t *cols, uint32_t n_cols, uint32_t *order) {
 
 // cols_dv: DEVICE pointer (already staged).  Emits the openings of rows [row_lo, row_hi).
 int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d,
-                         uint32_t row_lo, uint32_t row_hi, uint32_t skip_low = 0) {
+                         uint32_t row_lo, uint32_t row_hi) {
     zip_ctx *ctx = c->ctx;
     if (n_cols == 0 || row_hi <= row_lo) return ZIP_OK;
     OpenColsArgs a{};
@@ -1220,24 +1190,19 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
     } else {
         const CommitGeom cg = commit_geom(ctx->p.codeword_len, ctx->p.row_len);
         size_t used = (size_t)commit_wgs_per_cu(cg) * cg.lds;
-        const size_t rec = 8 + 32 * (size_t)(ctx->depth - skip_low);  // bytes of one record in the LDS image
-        if (c->direct) used += direct_lds_bytes(n_cols);  // zip_commit_open: the destination lists in LDS
+        const size_t rec = 8 + 32 * (size_t)ctx->depth;  // bytes of one record in the LDS image
         const size_t free_lds = used < 160u * 1024u ? 160u * 1024u - used : 0;
         // (2.5 KB of slack: LDS is handed out in granules -- 24 records = 10.7 KB did NOT get in beside 148.8 KB)
         while (rpb > 8 && rpb * rec + 2560 > free_lds) rpb -= 8;
-        // beside the direct commit kernel (8 KB of lists): two workgroups per CU rather than one with more rows
-        if (c->direct)
-            while (rpb > 8 && 2 * rpb * rec + 2560 > free_lds) rpb -= 8;
     }
     a.rows_per_block = (row_hi - row_lo) < rpb ? (row_hi - row_lo) : rpb;
     static const int knob_prio = getenv("ZIP_HIP_GATHER_PRIO") ? atoi(getenv("ZIP_HIP_GATHER_PRIO")) : 1;
     a.prio = (uint32_t)knob_prio;
-    a.skip_low = skip_low;
-    // The whole opening (skip_low == 0) where the commit kernel leaves little LDS (cw = 16384: 16 records per workgroup):
+    // Where the commit kernel leaves little LDS (cw = 16384: 16 records per workgroup):
     // the kernel without an LDS image.  ZIP_HIP_GATHER_STREAM=1 / 0 forces it on / off.
     static const int knob_stream = getenv("ZIP_HIP_GATHER_STREAM") ? atoi(getenv("ZIP_HIP_GATHER_STREAM")) : -1;
     const bool stream = knob_stream >= 0 ? knob_stream == 1 : rpb < 32;
-    if (stream && skip_low == 0 && ctx->depth >= 1 && 2 * ctx->depth + 3 <= 64) {
+    if (stream && ctx->depth >= 1 && 2 * ctx->depth + 3 <= 64) {
         const uint32_t want = (knob_rpb >= 2 && knob_rpb <= 4096) ? knob_rpb : 32u;
         a.rows_per_block = (row_hi - row_lo) < want ? (row_hi - row_lo) : want;
         const dim3 grid(n_cols, (row_hi - row_lo + a.rows_per_block - 1) / a.rows_per_block), block(256);
@@ -1249,7 +1214,7 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
         HIP_TRY(ctx, hipGetLastError());
         return ZIP_OK;
     }
-    const size_t lds = (size_t)a.rows_per_block * (8 + 32 * (size_t)(ctx->depth - skip_low));
+    const size_t lds = (size_t)a.rows_per_block * (8 + 32 * (size_t)ctx->depth);
     const dim3 grid(n_cols, (row_hi - row_lo + a.rows_per_block - 1) / a.rows_per_block), block(256);
     LaunchTimer t(ctx, "open_columns_kernel");
     if (2 * ctx->depth + 1 <= 32)
@@ -1262,17 +1227,12 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
 
 // All chunks, each gated on the arrival counter of the (possibly still running) persistent
 // commit kernel: the memory-bound gather of chunk k runs beside the hashing of later chunks.
-int32_t run_open_columns_pipelined(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d,
-                                   uint32_t skip_low = 0) {
+int32_t run_open_columns_pipelined(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d) {
     zip_ctx *ctx = c->ctx;
     if (!c->chunk_done || (c->ring_slot && c->ring_epoch != ctx->ring_epoch)) {
         int32_t rc = wait_ready(c, ctx->stream);
         if (rc) return rc;
-        if (skip_low && c->direct_from_row) {
-            if ((rc = run_open_columns(c, cols_dv, n_cols, out_d, 0, c->direct_from_row, 0))) return rc;
-            return run_open_columns(c, cols_dv, n_cols, out_d, c->direct_from_row, ctx->rows_local, skip_low);
-        }
-        return run_open_columns(c, cols_dv, n_cols, out_d, 0, ctx->rows_local, skip_low);
+        return run_open_columns(c, cols_dv, n_cols, out_d, 0, ctx->rows_local);
     }
     if (c->zeroed) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, c->zeroed, 0));
     // test hook: an unreachable target and a 1 ms limit exercise the recovery path of a timed-out wait
@@ -1285,8 +1245,7 @@ int32_t run_open_columns_pipelined(zip_commitment *c, const uint32_t *cols_dv, u
                                force_timeout ? 100000ull : 25000000ull /* 0.25 s at 100 MHz */);
             HIP_TRY(ctx, hipGetLastError());
         }
-        int32_t rc = run_open_columns(c, cols_dv, n_cols, out_d, c->bounds[k], c->bounds[k + 1],
-                                      c->bounds[k] >= c->direct_from_row ? skip_low : 0u);
+        int32_t rc = run_open_columns(c, cols_dv, n_cols, out_d, c->bounds[k], c->bounds[k + 1]);
         if (rc) return rc;
     }
     return ZIP_OK;
@@ -1300,20 +1259,14 @@ size_t column_bytes(const zip_ctx *ctx) {
 // kernel could not run -- which happens when something serialises kernel dispatch across streams
 // (rocprofv3 counter collection does, and may run the waiter first).  The gathers behind that wait
 // read rows that did not exist yet, so the whole gather is redone once the commit has really finished.
-int32_t recover_gather_timeout(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d,
-                               uint32_t skip_low = 0) {
+int32_t recover_gather_timeout(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d) {
     zip_ctx *ctx = c->ctx;
     HIP_TRY(ctx, stream_wait(ctx->stream));
     if (!(ctx->timeout_flag_h && *ctx->timeout_flag_h)) return ZIP_OK;
     *ctx->timeout_flag_h = 0;
     int32_t rc = wait_ready(c, ctx->stream);
     if (rc) return rc;
-    if (skip_low && c->direct_from_row) {
-        if ((rc = run_open_columns(c, cols_dv, n_cols, out_d, 0, c->direct_from_row, 0))) return rc;
-        if ((rc = run_open_columns(c, cols_dv, n_cols, out_d, c->direct_from_row, ctx->rows_local, skip_low))) return rc;
-    } else if ((rc = run_open_columns(c, cols_dv, n_cols, out_d, 0, ctx->rows_local, skip_low))) {
-        return rc;
-    }
+    if ((rc = run_open_columns(c, cols_dv, n_cols, out_d, 0, ctx->rows_local))) return rc;
     HIP_TRY(ctx, stream_wait(ctx->stream));
     return ZIP_OK;
 }
@@ -1899,12 +1852,9 @@ int32_t zip_ctx_synchronize(zip_ctx *ctx) {
 
 void *zip_ctx_stream(zip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
-// open_cols_d != nullptr (zip_commit_open): device address of the column openings inside the proof being written;
-// the commit kernel then puts the values and level-0..2 siblings of the hinted columns there (CommitArgs.open_cols).
 static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
                            int32_t with_merkle, const uint32_t *hint_cols, uint32_t n_hint, uint8_t *roots_out,
-                           zip_commitment **out, uint8_t *open_cols_d = nullptr) {
-    // (open_cols_d: zip_commit_open's proof stream, for the opt-in direct mode)
+                           zip_commitment **out) {
     if (!ctx || !out) return ZIP_ERR_NULL;
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -2013,11 +1963,10 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
             const uint32_t wv = (cw + 31) / 32, w1 = (cw / 2 + 31) / 32, w2 = (cw / 4 + 31) / 32;
             const size_t words = 2 * (size_t)wv + w1 + w2;
             if (words * 4 > kHintBytes) { rc = fail(ctx, ZIP_ERR_UNSUPPORTED, "hint bitmaps exceed their staging block"); break; }
-            const bool direct = open_cols_d && commit_supports_direct(ctx, n_hint);
-            const bool want_packed = !direct && c->compact_rows && n_hint && packed_enabled();
+            const bool want_packed = c->compact_rows && n_hint && packed_enabled();
             c->plan = get_hint_plan(ctx, hint_cols, n_hint, want_packed);
-            const bool resident = !direct && c->plan->dev;  // the tables already sit on the device (HintPlan::dev)
-            if (!resident) {  // per-commit staging block + upload: the direct mode's tables, or no device copy of the plan
+            const bool resident = c->plan->dev != nullptr;  // the tables already sit on the device (HintPlan::dev)
+            if (!resident) {  // per-commit staging block + upload: there is no device copy of the plan
                 if (!ctx->hint_free.empty()) {
                     c->hint_h = ctx->hint_free.back();
                     ctx->hint_free.pop_back();
@@ -2042,24 +1991,6 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
                 c->pk_stride = c->plan->L.stride;
                 for (int k = 0; k < 3; k++) c->pk_off[k] = c->plan->L.off[k];
             }
-            if (direct) {
-                // column -> openings lists (CommitArgs.open_tab): vp[cw / 32] | firstr[n] | next[n]
-                uint64_t *vp = reinterpret_cast<uint64_t *>(c->hint_h + kHintTables);
-                uint16_t *firstr = reinterpret_cast<uint16_t *>(vp + cw / 32), *next = firstr + n_hint;
-                std::vector<uint16_t> first_of(cw, 0xFFFF);
-                for (uint32_t i = n_hint; i-- > 0;) {  // backwards: the lists come out in opening order
-                    next[i] = first_of[hint_cols[i]];
-                    first_of[hint_cols[i]] = (uint16_t)i;
-                }
-                uint32_t rank = 0;
-                for (uint32_t w = 0; w < cw / 32; w++) {
-                    vp[w] = ((uint64_t)rank << 32) | nv[w];
-                    for (uint32_t b = 0; b < 32; b++)
-                        if ((nv[w] >> b) & 1u) firstr[rank++] = first_of[w * 32 + b];
-                }
-                for (uint32_t k = rank; k < n_hint; k++) firstr[k] = 0xFFFF;
-                upload = kHintTables + direct_table_bytes(cw, n_hint);
-            }
             const unsigned char *tables_d;
             if (resident) {
                 tables_d = c->plan->dev;
@@ -2079,21 +2010,6 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
                 a.pk_off2 = c->pk_off[2];
                 a.pk_tab = reinterpret_cast<const uint32_t *>(tables_d + kHintTables);
                 c->rank_d = reinterpret_cast<const uint16_t *>(tables_d + kPackedRanksAt);
-            }
-            if (direct) {
-                const uint32_t rec = 8 + 32 * ctx->depth;
-                a.open_cols = open_cols_d;
-                a.per_col = (uint64_t)R * (32 + rec);
-                a.rec_bytes = rec;
-                a.rows_total = R;
-                a.n_open = n_hint;
-                // ZIP_HIP_DIRECT=2: only the rows of the LAST chunk -- the ones whose gather ends the step
-                if (atoi(getenv("ZIP_HIP_DIRECT")) == 2 && nch > 1) a.direct_from_row = c->bounds[nch - 1];
-                c->direct_from_row = a.direct_from_row;
-                static const uint32_t exp_direct = getenv("ZIP_HIP_EXP_DIRECT") ? (uint32_t)atoi(getenv("ZIP_HIP_EXP_DIRECT")) : 0u;
-                a.exp_flags = exp_direct;
-                a.open_tab = reinterpret_cast<const uint64_t *>(reinterpret_cast<const unsigned char *>(c->need_d) + kHintTables);
-                c->direct = true;
             }
         }
         if (with_merkle && nch > 1) {
@@ -2180,7 +2096,6 @@ static int32_t rematerialize(zip_commitment *c) {
     zip_ctx *ctx = c->ctx;
     CommitArgs a = c->args;
     a.need = nullptr;
-    a.open_cols = nullptr;
     a.pk = nullptr;
     a.clock = nullptr;
     a.chunk_done = nullptr;  // the chunks of the first run stay published
@@ -2192,7 +2107,6 @@ static int32_t rematerialize(zip_commitment *c) {
     if (c->done) HIP_TRY(ctx, hipEventRecord(c->done, ctx->s_commit));
     HIP_TRY(ctx, stream_wait(ctx->s_commit));
     c->hinted = false;
-    c->direct = false;
     c->packed = false;
     return ZIP_OK;
 }
@@ -2200,7 +2114,6 @@ static int32_t rematerialize(zip_commitment *c) {
 // every column of cols[] lies inside the hint (host check); otherwise the handle is completed first
 static int32_t ensure_columns(zip_commitment *c, const uint32_t *cols, uint32_t n_cols) {
     if (!c->hinted) return ZIP_OK;
-    if (c->direct) return rematerialize(c);  // the low levels of the hinted columns only exist in that call's proof
     // ... a packed handle serves the openings it was hinted with, in their order (rank_d); anything else completes it
     if (c->packed)
         return (c->plan && c->plan->cols.size() == n_cols && (n_cols == 0 || !memcmp(c->plan->cols.data(), cols, (size_t)n_cols * 4)))
@@ -2457,11 +2370,10 @@ size_t zip_proof_len(const zip_ctx *ctx, uint32_t n_cols, uint32_t field_limbs) 
 }
 
 // The body of MultilinearZip::open with everything on the device: row combinations, column openings (pipelined behind
-// the commit kernel), evaluation row -> out_d.  skip_low != 0: the values and the siblings below that level are already
-// in out_d (zip_commit_open).  Returns after the stream has drained (the small host inputs have been consumed).
+// the commit kernel), evaluation row -> out_d.  Returns after the stream has drained (the small host inputs have
+// been consumed).
 static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int64_t *coeffs, const uint32_t *cols,
-                           uint32_t n_cols, const uint64_t *q0_mont, const HostField &hf, uint8_t *out_d,
-                           uint32_t skip_low) {
+                           uint32_t n_cols, const uint64_t *q0_mont, const HostField &hf, uint8_t *out_d) {
     zip_ctx *ctx = c->ctx;
     int32_t rc;
     const bool single = ctx->p.num_rows == 1;
@@ -2532,7 +2444,7 @@ static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int6
         HIP_TRY(ctx, hipEventRecord(combined, ctx->s_aux));
     }
     if ((rc = run_open_columns_pipelined(c, reinterpret_cast<const uint32_t *>(sb + si.off[2]), n_cols,
-                                         out_d + u_bytes, skip_low)))
+                                         out_d + u_bytes)))
         return rc;
     if (place == 2) {
         if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o))) return rc;
@@ -2550,8 +2462,7 @@ static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int6
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, combined, 0));
     }
     // synchronises: the small host inputs (coeffs, cols, q0) have been consumed
-    if ((rc = recover_gather_timeout(c, reinterpret_cast<const uint32_t *>(sb + si.off[2]), n_cols, out_d + u_bytes,
-                                     skip_low)))
+    if ((rc = recover_gather_timeout(c, reinterpret_cast<const uint32_t *>(sb + si.off[2]), n_cols, out_d + u_bytes)))
         return rc;
     return ZIP_OK;
 }
@@ -2586,7 +2497,7 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
     }
     if ((rc = check_cols(ctx, cols, n_cols))) return rc;
     if ((rc = ensure_columns(c, cols, n_cols))) return rc;
-    if ((rc = open_device(c, evals_d, coeffs, cols, n_cols, q0_mont, hf, out_d, 0))) return rc;
+    if ((rc = open_device(c, evals_d, coeffs, cols, n_cols, q0_mont, hf, out_d))) return rc;
     if (out_kind == ZIP_MEM_HOST) return deliver(ctx, proof_out, ZIP_MEM_HOST, out_d, total);
     return ZIP_OK;
 }
@@ -2613,13 +2524,12 @@ int32_t zip_commit_open(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_
         if ((rc = res.get(total))) return rc;
         out_d = res.as<uint8_t>();
     }
-    const size_t u_bytes = single ? 0 : (size_t)ctx->p.row_len * ctx->p.m_limbs * 8;
     static const uint32_t none = 0;
     zip_commitment *c = nullptr;
-    if ((rc = commit_impl(ctx, evals, n_evals, evals_kind, 1, cols ? cols : &none, n_cols, nullptr, &c, out_d + u_bytes)))
+    if ((rc = commit_impl(ctx, evals, n_evals, evals_kind, 1, cols ? cols : &none, n_cols, nullptr, &c)))
         return rc;
     const int64_t *evals_d = c->evals ? c->evals : c->evals_ref;
-    rc = open_device(c, evals_d, coeffs, cols, n_cols, q0_mont, hf, out_d, c->direct ? 3u : 0u);
+    rc = open_device(c, evals_d, coeffs, cols, n_cols, q0_mont, hf, out_d);
     if (!rc && roots_out) {
         rc = wait_ready(c, ctx->stream);
         if (!rc) rc = deliver(ctx, roots_out, ZIP_MEM_HOST, c->roots, c->roots_bytes);
