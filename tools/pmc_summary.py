@@ -55,7 +55,7 @@ def classify(kernel):
         else:  # <E, HASH, MODE>: 0 everything stored, 1 hinted at the natural places, 3 hinted and packed
             mode = {"0": "plain", "1": "hinted", "3": "packed"}.get(args[2] if len(args) > 2 else "0", "plain")
         return "raa_commit_kernel", mode
-    if "open_columns_kernel" in k:
+    if "open_columns_kernel" in k or "open_columns_stream_kernel" in k:
         return "open_columns_kernel", "any"
     return None
 
