@@ -222,6 +222,9 @@ def main():
                     help="zip_commit_hinted + zip_open instead of zip_commit_open (values / low siblings via the trees)")
     ap.add_argument("--no-hint", action="store_true",
                     help="plain zip_commit (every row entry and tree node stored) instead of zip_commit_hinted")
+    ap.add_argument("--no-pipelined", action="store_true",
+                    help="skip the extra leg that runs the same steps as jobs, two in flight (zip_commit_open_begin / "
+                         "zip_job_wait); it is reported beside `value`, never as it")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="extra leg (1 GPU, reported beside `value`, never as it): this many independent commit+open jobs "
                          "in flight at once, one zip_ctx and one host thread each")
@@ -336,6 +339,31 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    pipelined = None
+    if not args.no_pipelined and world == 1 and not rows_mode and not (args.two_calls or args.no_hint):
+        # The same K steps as jobs, two in flight: the next polynomial's commit kernel is queued behind the current
+        # one's and runs beside the end of its openings (the last chunk's gather).  Throughput of a prover that has a
+        # queue of polynomials; `value` above stays the one-proof-at-a-time figure.
+        proofs2 = [proof, torch.empty_like(proof)]
+        torch.cuda.synchronize()
+        for k in (2, args.steps):  # warm-up, then the timed run
+            barrier()
+            t1 = time.perf_counter()
+            pending = []
+            for i in range(k):
+                if len(pending) == 2:
+                    pending.pop(0).wait()
+                pending.append(ctx.commit_open_begin(evals_d, coeffs, cols, q0, zf, proofs2[i & 1]))
+            for j in pending:
+                j.wait()
+            barrier()
+            dtp = time.perf_counter() - t1
+        pipelined = {"jobs_in_flight": 2, "steps": args.steps, "ms_per_step": round(dtp / args.steps * 1e3, 4),
+                     "value": round(n * args.steps / dtp / 1e6, 2), "unit": "MCoeffs/s",
+                     "proofs_identical": bool(torch.equal(proofs2[0], proofs2[1])),
+                     "api": "zip_commit_open_begin / zip_job_wait",
+                     "note": "the same steps queued as jobs, two in flight; `value` above is one proof at a time"}
 
     in_flight = None
     if args.in_flight > 1 and world == 1 and not rows_mode:
@@ -454,6 +482,8 @@ def main():
                            "hbm_frac": round(sum(ab.values()) / step_s / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(ktimes.items())},
         }
+        if pipelined:
+            out["pipelined"] = pipelined
         if in_flight:
             out["in_flight"] = in_flight
         if not args.no_cpu_baseline and world == 1:

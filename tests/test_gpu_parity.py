@@ -452,6 +452,47 @@ def test_commit_open_in_one_call_is_byte_identical(cabi, geometry, device_out, p
     assert none is None and np.array_equal(proof2, proof_o)
 
 
+@pytest.mark.parametrize("num_vars", [12, 18, 22])
+def test_jobs_in_flight_produce_the_same_proofs(cabi, num_vars):
+    """zip_commit_open_begin / zip_job_wait: four different polynomials, two jobs in flight at any time (the second
+    commit kernel queued behind the first, beside the first one's last openings).  Every proof and every root equals
+    what the one-call zip_commit_open gives for that polynomial (itself diffed against the oracle above); a third
+    begin while two jobs are in flight is refused; 2^22 has two chunks, so the overlap is the real one."""
+    torch = pytest.importorskip("torch")
+    z = orc.Zip(num_vars)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    point = orc.point_to_field(f, np.arange(-7, num_vars - 7, dtype=np.int64))
+    lr = z.num_rows.bit_length() - 1
+    q0 = orc.build_eq_x_r(f, point[num_vars - lr:])
+    rng = np.random.default_rng(5)
+    coeffs = rng.integers(-(1 << 62), 1 << 62, size=z.num_rows, dtype=np.int64)
+    cols = rng.integers(0, z.codeword_len, size=1000, dtype=np.uint32)
+    ctx = _ctx(cabi, z)
+    witnesses = [torch.from_numpy(_witness(num_vars, seed=40 + i)).cuda() for i in range(4)]
+    want = []
+    for w in witnesses:
+        proof, roots, _ = ctx.commit_open(w, coeffs, cols, q0, zf)
+        want.append((proof.copy() if isinstance(proof, np.ndarray) else proof.cpu().numpy(), roots))
+    outs = [torch.full((want[0][0].size,), 0xA5, dtype=torch.uint8, device="cuda") for _ in witnesses]
+    torch.cuda.synchronize()  # the fills run on torch's stream, the library on its own
+    jobs = [ctx.commit_open_begin(witnesses[0], coeffs, cols, q0, zf, outs[0]),
+            ctx.commit_open_begin(witnesses[1], coeffs, cols, q0, zf, outs[1])]
+    with pytest.raises(cabi.ZipError):
+        ctx.commit_open_begin(witnesses[2], coeffs, cols, q0, zf, outs[2])
+    got_roots = [jobs[0].wait(want_roots=True)]
+    jobs.append(ctx.commit_open_begin(witnesses[2], coeffs, cols, q0, zf, outs[2]))
+    got_roots.append(jobs[1].wait(want_roots=True))
+    jobs.append(ctx.commit_open_begin(witnesses[3], coeffs, cols, q0, zf, outs[3]))
+    got_roots.append(jobs[2].wait(want_roots=True))
+    got_roots.append(jobs[3].wait(want_roots=True))
+    ctx.synchronize()
+    for i in range(4):
+        assert np.array_equal(got_roots[i], want[i][1]), i
+        bad = np.flatnonzero(outs[i].cpu().numpy() != want[i][0])
+        assert bad.size == 0, f"job {i}: {bad.size} proof bytes differ, first at {bad[:8]}"
+
+
 @pytest.mark.parametrize("num_vars", [12, 16, 18])
 @pytest.mark.parametrize("shards", [1, 2, 3, 4, 8])
 def test_multi_device_context_proof_equals_unsharded(cabi, num_vars, shards):

@@ -25,7 +25,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 
 EXPORTED_SYMBOLS = (
     "zip_abi_version", "zip_strerror", "zip_device_count", "zip_release_cached_memory", "zip_host_register", "zip_host_unregister", "zip_ctx_create", "zip_ctx_destroy",
-    "zip_ctx_last_error", "zip_ctx_synchronize", "zip_ctx_stream", "zip_commit", "zip_commit_hinted", "zip_commit_open", "zip_commitment_free",
+    "zip_ctx_last_error", "zip_ctx_synchronize", "zip_ctx_stream", "zip_commit", "zip_commit_hinted", "zip_commit_open", "zip_commit_open_begin", "zip_job_wait", "zip_commitment_free",
     "zip_commitment_device_ptrs", "zip_commit_download", "zip_commitment_upload", "zip_open_testing",
     "zip_open_columns", "zip_open_eval", "zip_proof_len", "zip_open", "zip_sum_partials", "zip_merkle_trees",
     "zip_ctx_set_profiling", "zip_ctx_profile_read", "zip_ctx_commit_clock",
@@ -35,6 +35,23 @@ EXPORTED_SYMBOLS = (
     "zip_ccs_create", "zip_ccs_free", "zip_ccs_last_error", "zip_ccs_set_z", "zip_ccs_eq_table",
     "zip_ccs_second_table", "zip_ccs_table", "zip_ccs_download", "zip_ccs_eval_matrices",
 )
+
+
+class Job:
+    """A zip_commit_open in flight (ZipContext.commit_open_begin)."""
+
+    def __init__(self, ctx, handle, keep):
+        self._ctx, self._h, self._keep = ctx, handle, keep
+
+    def wait(self, want_roots=False):
+        """-> roots (numpy) or None; the proof is in the buffer given to commit_open_begin."""
+        assert self._h is not None, "job already waited for"
+        roots = np.zeros((self._ctx.rows_local, 32), dtype=np.uint8) if want_roots else None
+        h, self._h = self._h, None
+        rc = lib().zip_job_wait(h, roots.ctypes.data if roots is not None else None)
+        self._keep = None
+        self._ctx._check(rc, "zip_job_wait")
+        return roots
 
 
 class ZipError(RuntimeError):
@@ -140,6 +157,10 @@ def lib():
     L.zip_commit_open.argtypes = [vp, i64p, C.c_size_t, C.c_int, i64p, u32p, C.c_uint32, u64p, C.POINTER(ZipField), u8p, vp,
                                   C.c_int, C.POINTER(vp)]
     L.zip_commit_open.restype = C.c_int32
+    L.zip_commit_open_begin.argtypes = [vp, i64p, C.c_size_t, i64p, u32p, C.c_uint32, u64p, C.POINTER(ZipField), vp, C.POINTER(vp)]
+    L.zip_commit_open_begin.restype = C.c_int32
+    L.zip_job_wait.argtypes = [vp, u8p]
+    L.zip_job_wait.restype = C.c_int32
     L.zip_verify.argtypes = [vp, u8p, vp, C.c_int, C.c_size_t, i64p, u32p, C.c_uint32, u64p, u64p, u64p,
                              C.POINTER(ZipField), C.POINTER(VerifyReport)]
     L.zip_mle_eval.argtypes = [vp, i64p, C.c_int, u64p, u64p, C.POINTER(ZipField), u64p]
@@ -339,6 +360,22 @@ class ZipContext:
                                    C.byref(h) if keep else None)
         self._check(rc, "zip_commit_open")
         return res, roots, (Commitment(self, h, True) if keep else None)
+
+    def commit_open_begin(self, evals_d, coeffs, cols, q0_mont, field, out_d):
+        """zip_commit_open_begin: the whole commit + open of a DEVICE witness into a DEVICE proof buffer is enqueued; the
+        returned Job's wait() collects it.  Two jobs per ctx may be in flight."""
+        ptr, kind = _ptr(evals_d)
+        optr, okind = _ptr(out_d)
+        assert kind == MEM_DEVICE and okind == MEM_DEVICE, "jobs take device memory"
+        cols = np.ascontiguousarray(cols, dtype=np.uint32)
+        coeffs_c = np.ascontiguousarray(coeffs, dtype=np.int64) if coeffs is not None else None
+        q0 = np.ascontiguousarray(q0_mont, dtype=np.uint64) if q0_mont is not None else None
+        h = C.c_void_p()
+        rc = lib().zip_commit_open_begin(self._h, ptr, evals_d.numel(), coeffs_c.ctypes.data if coeffs_c is not None else None,
+                                         cols.ctypes.data, cols.size, q0.ctypes.data if q0 is not None else None, C.byref(field),
+                                         optr, C.byref(h))
+        self._check(rc, "zip_commit_open_begin")
+        return Job(self, h, (evals_d, out_d))
 
     def upload_commitment(self, rows, layers=None, roots=None):
         # keep every (possibly copied) array alive across the call

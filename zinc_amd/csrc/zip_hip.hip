@@ -114,6 +114,10 @@ struct zip_ctx {
     // are gone, its openings then wait for the whole commit instead)
     uint32_t *ring_d = nullptr;
     uint32_t ring_next = 0, ring_epoch = 0;
+    // zip_commit_open_begin: pinned staging of the jobs in flight (kJobSlots), and which slots are taken
+    unsigned char *job_stage[2] = {nullptr, nullptr};
+    bool job_busy[2] = {false, false};
+    bool job_redo = false;  // a pipeline wait gave up while several jobs were in flight: the next one re-gathers too
     // make_field memo: the last zip_field seen and what FieldConfig::new made of it (a HostField, kept as bytes here
     // because that type is defined further down)
     zip_field field_cache_in{};
@@ -154,6 +158,7 @@ struct zip_commitment {
     uint32_t *chunk_done = nullptr;  // device arrival counters (a pool block, or a slot of the ctx's ring)
     bool ring_slot = false;
     uint32_t ring_epoch = 0;
+    bool consumers_done = false;  // set by zip_job_wait: nothing on the ctx's streams still reads this handle
     hipEvent_t zeroed = nullptr;     // counters reset (consumers must not look at stale values)
     hipEvent_t done = nullptr;       // whole commit finished
     std::vector<hipEvent_t> aux;     // other events owned by the handle, recycled with it
@@ -402,15 +407,19 @@ struct SmallInputs {
     size_t bytes[N] = {};
     size_t off[N] = {};
 };
-int32_t stage_small(zip_ctx *ctx, SmallInputs &in, Scratch &dev, unsigned char **base) {
+// own_stage / own_cap: a pinned buffer of the caller's instead of the ctx's (a job that returns before the copy has run)
+int32_t stage_small(zip_ctx *ctx, SmallInputs &in, Scratch &dev, unsigned char **base, unsigned char *own_stage = nullptr,
+                    size_t own_cap = 0) {
     size_t total = 0;
     for (int i = 0; i < SmallInputs::N; i++) {
         in.off[i] = total;
         total += (in.bytes[i] + 255) & ~(size_t)255;
     }
     if (total == 0) { *base = nullptr; return ZIP_OK; }
-    unsigned char *stage = ctx->stage_h;
-    if (total > ctx->stage_cap) {
+    unsigned char *stage = own_stage ? own_stage : ctx->stage_h;
+    if (own_stage) {
+        if (total > own_cap) return fail(ctx, ZIP_ERR_UNSUPPORTED, "small inputs (%zu bytes) exceed a job's staging block", total);
+    } else if (total > ctx->stage_cap) {
         // larger than the block allocated with the ctx (which also holds the timeout flag and
         // stays where it is): a second pinned buffer, grown on demand
         if (total > ctx->stage_big_cap) {
@@ -1816,6 +1825,8 @@ void zip_ctx_destroy(zip_ctx *ctx) {
     if (ctx->s_aux) (void)hipStreamDestroy(ctx->s_aux);
     if (ctx->stage_big) (void)hipHostFree(ctx->stage_big);
     for (auto *h : ctx->hint_free) (void)hipHostFree(h);
+    for (auto *h : ctx->job_stage)
+        if (h) (void)hipHostFree(h);
     if (ctx->ring_d) (void)hipFree(ctx->ring_d);
     ctx->hint_plan.reset();
     if (ctx->pinned_base) (void)hipHostFree(ctx->pinned_base);
@@ -2135,7 +2146,7 @@ void zip_commitment_free(zip_commitment *c) {
     }
     if (c->zeroed) c->ctx->dep_event_pool.push_back(c->zeroed);
     for (hipEvent_t e : c->aux) c->ctx->dep_event_pool.push_back(e);
-    if (c->ctx->stream) (void)stream_wait(c->ctx->stream);
+    if (c->ctx->stream && !c->consumers_done) (void)stream_wait(c->ctx->stream);
     if (!c->ring_slot) pool_release(c->ctx, c->chunk_done);
     pool_release(c->ctx, c->need_d);
     if (c->hint_h) c->ctx->hint_free.push_back(c->hint_h);
@@ -2370,10 +2381,23 @@ size_t zip_proof_len(const zip_ctx *ctx, uint32_t n_cols, uint32_t field_limbs) 
 }
 
 // The body of MultilinearZip::open with everything on the device: row combinations, column openings (pipelined behind
-// the commit kernel), evaluation row -> out_d.  Returns after the stream has drained (the small host inputs have
-// been consumed).
-static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int64_t *coeffs, const uint32_t *cols,
-                           uint32_t n_cols, const uint64_t *q0_mont, const HostField &hf, uint8_t *out_d) {
+// the commit kernel), evaluation row -> out_d.  open_enqueue puts all of it on the streams (OpenState holds what must
+// outlive the launches), open_finish waits for it; open_device is the two together.
+struct OpenState {
+    Scratch small;
+    // declared last = destroyed first: on every path the combination enqueued on s_aux has drained before `small`
+    // (its inputs) and its own partial sums go back to the pool
+    CombineScratch cscr;
+    const uint32_t *cols_dv = nullptr;
+    uint32_t n_cols = 0;
+    uint8_t *openings_d = nullptr;
+    explicit OpenState(zip_ctx *c) : small(c), cscr(c) {}
+};
+constexpr size_t kJobStageBytes = (size_t)1 << 20;
+
+static int32_t open_enqueue(zip_commitment *c, const int64_t *evals_d, const int64_t *coeffs, const uint32_t *cols,
+                            uint32_t n_cols, const uint64_t *q0_mont, const HostField &hf, uint8_t *out_d, OpenState &st,
+                            unsigned char *own_stage = nullptr) {
     zip_ctx *ctx = c->ctx;
     int32_t rc;
     const bool single = ctx->p.num_rows == 1;
@@ -2382,10 +2406,8 @@ static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int6
     CombineOut o{};
     o.uprime = single ? nullptr : reinterpret_cast<uint64_t *>(out_d);
     o.row_be = out_d + u_bytes + col_bytes;
-    Scratch small(ctx);
-    // declared last = destroyed first: on every return path the combination enqueued on s_aux has drained before
-    // `small`, `ev` and `res` (its inputs and output) and its own partial sums go back to the pool
-    CombineScratch cscr(ctx);
+    Scratch &small = st.small;
+    CombineScratch &cscr = st.cscr;
     SmallInputs si;
     if (!single) {
         si.src[0] = coeffs;
@@ -2404,12 +2426,11 @@ static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int6
         si.bytes[3] = (size_t)n_cols * 4;
     }
     unsigned char *sb;
-    if ((rc = stage_small(ctx, si, small, &sb))) return rc;
-    struct OrderScope {  // the tables live in `small`: no launch may see them after this call
-        zip_commitment *c;
-        ~OrderScope() { c->gather_order = nullptr; }
-    } order_scope{c};
-    c->gather_order = order.empty() ? nullptr : reinterpret_cast<const uint32_t *>(sb + si.off[3]);
+    if ((rc = stage_small(ctx, si, small, &sb, own_stage, own_stage ? kJobStageBytes : 0))) return rc;
+    c->gather_order = order.empty() ? nullptr : reinterpret_cast<const uint32_t *>(sb + si.off[3]);  // (lives in `small`)
+    st.cols_dv = reinterpret_cast<const uint32_t *>(sb + si.off[2]);
+    st.n_cols = n_cols;
+    st.openings_d = out_d + u_bytes;
     // The two row combinations do not depend on the commitment.  Where to put them (ZIP_HIP_COMBINE):
     //   split (default) the pass over the witness FIRST on the main stream -- the stream would otherwise idle until the
     //                   commit kernel publishes its first chunk, and with s_setprio the pass is not starved by the
@@ -2461,10 +2482,23 @@ static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int6
     } else if (place == 1 || place == 3) {
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, combined, 0));
     }
-    // synchronises: the small host inputs (coeffs, cols, q0) have been consumed
-    if ((rc = recover_gather_timeout(c, reinterpret_cast<const uint32_t *>(sb + si.off[2]), n_cols, out_d + u_bytes)))
-        return rc;
     return ZIP_OK;
+}
+// synchronises: the small host inputs (coeffs, cols, q0) have been consumed, every launch has run
+static int32_t open_finish(zip_commitment *c, OpenState &st) {
+    const int32_t rc = recover_gather_timeout(c, st.cols_dv, st.n_cols, st.openings_d);
+    c->gather_order = nullptr;  // the table lives in st.small
+    return rc;
+}
+static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int64_t *coeffs, const uint32_t *cols,
+                           uint32_t n_cols, const uint64_t *q0_mont, const HostField &hf, uint8_t *out_d) {
+    OpenState st(c->ctx);
+    int32_t rc = open_enqueue(c, evals_d, coeffs, cols, n_cols, q0_mont, hf, out_d, st);
+    if (rc) {
+        c->gather_order = nullptr;
+        return rc;
+    }
+    return open_finish(c, st);
 }
 
 int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kind, const int64_t *coeffs,
@@ -2544,6 +2578,98 @@ int32_t zip_commit_open(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_
     }
     *out = c;
     return ZIP_OK;
+}
+
+// ---- zip_commit_open as a job: begin enqueues, wait collects (include/zip_hip.h) ---------------------------------
+struct zip_job {
+    zip_ctx *ctx = nullptr;
+    zip_commitment *c = nullptr;
+    OpenState *st = nullptr;
+    hipEvent_t finished = nullptr;  // behind the last launch of the open on the main stream
+    int slot = -1;
+};
+int32_t zip_commit_open_begin(zip_ctx *ctx, const int64_t *evals_d, size_t n_evals, const int64_t *coeffs, const uint32_t *cols,
+                              uint32_t n_cols, const uint64_t *q0_mont, const zip_field *field, uint8_t *proof_out_d,
+                              zip_job **out) {
+    if (!ctx || !out || !proof_out_d || !evals_d || (n_cols && !cols)) return ZIP_ERR_NULL;
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
+    if (ctx->rows_local != ctx->p.num_rows) return fail(ctx, ZIP_ERR_INVALID_PARAM, "zip_commit_open_begin needs an unsharded ctx");
+    HostField hf;
+    int32_t rc;
+    if ((rc = make_field(ctx, field, &hf))) return rc;
+    const bool single = ctx->p.num_rows == 1;
+    if (!single && (!coeffs || !q0_mont)) return fail(ctx, ZIP_ERR_NULL, "coeffs / q0_mont is NULL");
+    if ((rc = check_cols(ctx, cols, n_cols))) return rc;
+    int slot = !ctx->job_busy[0] ? 0 : !ctx->job_busy[1] ? 1 : -1;
+    if (slot < 0) return fail(ctx, ZIP_ERR_INVALID_PARAM, "two jobs are already in flight on this ctx: zip_job_wait one first");
+    if (!ctx->job_stage[slot] &&
+        hipHostMalloc((void **)&ctx->job_stage[slot], kJobStageBytes, hipHostMallocDefault) != hipSuccess) {
+        ctx->job_stage[slot] = nullptr;
+        return fail(ctx, ZIP_ERR_ALLOC, "hipHostMalloc(%zu) failed", kJobStageBytes);
+    }
+    zip_job *j = new (std::nothrow) zip_job();
+    if (!j) return ZIP_ERR_ALLOC;
+    j->ctx = ctx;
+    static const uint32_t none = 0;
+    if ((rc = commit_impl(ctx, evals_d, n_evals, ZIP_MEM_DEVICE, 1, cols ? cols : &none, n_cols, nullptr, &j->c))) {
+        delete j;
+        return rc;
+    }
+    j->st = new (std::nothrow) OpenState(ctx);
+    if (!j->st) rc = ZIP_ERR_ALLOC;
+    if (!rc) rc = open_enqueue(j->c, evals_d, coeffs, cols, n_cols, q0_mont, hf, proof_out_d, *j->st, ctx->job_stage[slot]);
+    if (!rc) {
+        j->finished = take_dep_event(ctx);
+        if (hipEventRecord(j->finished, ctx->stream) != hipSuccess) rc = fail(ctx, ZIP_ERR_HIP, "hipEventRecord failed");
+    }
+    if (rc) {  // (the destructors drain what was enqueued)
+        const std::string keep = ctx->last_error;
+        j->c->gather_order = nullptr;
+        delete j->st;
+        zip_commitment_free(j->c);
+        if (j->finished) ctx->dep_event_pool.push_back(j->finished);
+        delete j;
+        ctx->last_error = keep;
+        return rc;
+    }
+    ctx->job_busy[slot] = true;
+    j->slot = slot;
+    *out = j;
+    return ZIP_OK;
+}
+
+int32_t zip_job_wait(zip_job *j, uint8_t *roots_out) {
+    if (!j) return ZIP_ERR_NULL;
+    zip_ctx *ctx = j->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
+    int32_t rc = ZIP_OK;
+    hipError_t e = event_wait(j->finished);  // NOT the stream: the next job may already be queued behind this one
+    if (e != hipSuccess) rc = fail(ctx, ZIP_ERR_HIP, "job failed: %s", hipGetErrorString(e));
+    if (!rc && ((ctx->timeout_flag_h && *ctx->timeout_flag_h) || ctx->job_redo)) {
+        // a pipeline wait gave up (counter collection serialises the streams): everything in flight is redone
+        ctx->job_redo = ctx->job_busy[0] && ctx->job_busy[1];
+        rc = open_finish(j->c, *j->st);  // (synchronises the streams)
+    }
+    if (!rc && roots_out) {
+        if (!(rc = wait_ready(j->c, ctx->stream))) rc = deliver(ctx, roots_out, ZIP_MEM_HOST, j->c->roots, j->c->roots_bytes);
+    }
+    // everything of this job on the main and the fold stream has run: nothing to drain, nothing to wait for
+    const std::string keep = ctx->last_error;
+    j->c->gather_order = nullptr;
+    if (!rc) {
+        j->st->cscr.drain = nullptr;
+        j->c->consumers_done = true;
+    }
+    delete j->st;
+    zip_commitment_free(j->c);
+    ctx->dep_event_pool.push_back(j->finished);
+    ctx->job_busy[j->slot] = false;
+    ctx->last_error = keep;
+    delete j;
+    return rc;
 }
 
 // =====================================================================================================
