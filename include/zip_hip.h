@@ -409,7 +409,9 @@ int32_t zip_merkle_trees(int32_t device, const uint64_t *leaves, uint32_t leaf_l
                          uint32_t num_trees, zip_mem_kind kind, uint8_t *layers_out);
 
 /* ---- measurement hooks ---------------------------------------------------------------
- * With profiling on, every kernel launch is bracketed by HIP events on the ctx stream.
+ * With profiling on (1), every kernel launch is bracketed by HIP events on the stream it is launched on; with on = 2
+ * only the commit / encode kernel is (it has its stream to itself: between the kernels of ONE stream the events cost
+ * every dependent launch about 12 us, which a timed region need not pay).
  * zip_ctx_profile_read synchronises, then fills up to cap entries (kernel name, launch
  * count, total ms) and resets the counters; returns the number of distinct kernels. */
 typedef struct {
