@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -64,10 +65,11 @@ struct HintPlan {
     std::vector<uint16_t> own_ranks; // pk_rank of cols[] themselves, [n][4] (OpenColsArgs.pk_rank)
     // device copy, made once: bm at 0 (CommitArgs.need), wave_tab at kHintTables, own_ranks at kPackedRanksAt
     unsigned char *dev = nullptr;
+    std::function<void(unsigned char *)> release;  // gives `dev` back to its ctx's block pool (hipFree would stall the device)
     HintPlan() = default;
     HintPlan(const HintPlan &) = delete;
     HintPlan &operator=(const HintPlan &) = delete;
-    ~HintPlan() { if (dev) (void)hipFree(dev); }
+    ~HintPlan() { if (dev && release) release(dev); }
     // pk_rank of cs[i]: place of its value and of its three lowest siblings
     bool ranks(const uint32_t *cs, uint32_t n, uint16_t *out) const {
         for (uint32_t i = 0; i < n; i++) {
@@ -108,6 +110,7 @@ struct zip_ctx {
     unsigned char *bounce[2] = {nullptr, nullptr};
     size_t bounce_cap = 0;
     std::vector<unsigned char *> hint_free;  // pinned kHintBytes blocks of dead hinted commitments
+    std::shared_ptr<bool> alive = std::make_shared<bool>(true);  // false once zip_ctx_destroy has run
     bool profile_commit_only = false;  // zip_ctx_set_profiling(ctx, 2)
     std::shared_ptr<HintPlan> hint_plan;  // what the last hinted commit derived from its column list (memo)
     // chunk arrival counters of the persistent commit kernel: kRingSlots zeroed blocks of kRingStride counters, handed
@@ -934,14 +937,16 @@ static std::shared_ptr<HintPlan> get_hint_plan(zip_ctx *ctx, const uint32_t *col
         memcpy(img.data() + kPackedRanksAt, P->own_ranks.data(), P->own_ranks.size() * 2);
         used = kPackedRanksAt + P->own_ranks.size() * 2;
     }
-    if (used <= kHintBytes && hipMalloc((void **)&P->dev, kHintBytes) == hipSuccess) {
-        if (hipMemcpy(P->dev, img.data(), used, hipMemcpyHostToDevice) != hipSuccess) {
-            (void)hipFree(P->dev);
-            P->dev = nullptr;
+    void *blk = nullptr;
+    if (used <= kHintBytes && pool_alloc(ctx, kHintBytes, &blk) == ZIP_OK) {
+        if (hipMemcpy(blk, img.data(), used, hipMemcpyHostToDevice) == hipSuccess) {
+            P->dev = static_cast<unsigned char *>(blk);
+            std::shared_ptr<bool> alive = ctx->alive;  // (a handle that outlives its ctx must not touch the ctx's pool)
+            P->release = [ctx, alive](unsigned char *p) { if (*alive) pool_release(ctx, p); };
+        } else {
+            pool_release(ctx, blk);
+            (void)hipGetLastError();
         }
-    } else {
-        P->dev = nullptr;
-        (void)hipGetLastError();
     }
     ctx->hint_plan = P;
     return P;
@@ -1811,6 +1816,8 @@ void zip_ctx_destroy(zip_ctx *ctx) {
     if (ctx->s_upper) (void)stream_wait(ctx->s_upper);
     if (ctx->s_aux) (void)stream_wait(ctx->s_aux);
     if (ctx->stream) (void)stream_wait(ctx->stream);
+    ctx->hint_plan.reset();  // (its device block goes back to the pool that is torn down next)
+    *ctx->alive = false;
     if (ctx->recycle) {
         for (auto &kv : ctx->free_blocks) recycle_give(ctx->device, kv.first, kv.second);
         for (auto &kv : ctx->live_blocks) recycle_give(ctx->device, kv.second, kv.first);
@@ -1832,7 +1839,6 @@ void zip_ctx_destroy(zip_ctx *ctx) {
     for (auto *h : ctx->job_stage)
         if (h) (void)hipHostFree(h);
     if (ctx->ring_d) (void)hipFree(ctx->ring_d);
-    ctx->hint_plan.reset();
     if (ctx->pinned_base) (void)hipHostFree(ctx->pinned_base);
     if (ctx->recycle && ctx->bounce[0] && ctx->bounce[1] && ctx->device >= 0 && ctx->device < kMaxDevices) {
         RecycleBin &bin = g_recycle[ctx->device];
