@@ -259,3 +259,33 @@ def test_commit_open_2pow22_pipelined_gather_byte_diff(env, hinted, monkeypatch)
     rep = ctx.verify(roots, proof, coeffs, cols, q0, q1, np.array(orc.int_to_limbs(ev, 4), dtype=np.uint64), zf)
     assert rep == {"verdict": cabi.VERIFY_ACCEPT, "column": 0, "bad_merkle_paths": 0, "malformed_paths": 0}
     com.free()
+
+
+def test_handle_opened_after_its_chunk_counters_were_recycled(env):
+    """The chunk counters of a pipelined commit come from a ring of 64 pre-zeroed slots per ctx.  A handle that is opened
+    only after 70 further commits finds its counters gone (new ring epoch): its openings then wait for the whole commit
+    instead of polling them -- same bytes as an immediate open."""
+    cabi, torch = env
+    nv = 22
+    z = orc.Zip(nv)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    evals = orc.splitmix64(0x5A494E43 + 7, 1 << nv)
+    coeffs, cols, point, q0, q1 = _squeeze_open_inputs(z, f, nv)
+    ctx = cabi.ZipContext(nv, z.perm1, z.perm2)
+    d_evals = torch.from_numpy(evals).cuda()
+    first = torch.empty(ctx.proof_len(1000, 4), dtype=torch.uint8, device="cuda")
+    late = torch.full_like(first, 0x77)
+    torch.cuda.synchronize()
+    kept, _ = ctx.commit(d_evals, want_roots=False, hint_cols=cols)
+    for _ in range(70):
+        com, _ = ctx.commit(d_evals, want_roots=False, hint_cols=cols)
+        com.free()
+    now, _ = ctx.commit(d_evals, want_roots=False, hint_cols=cols)
+    now.open(d_evals, coeffs, cols, q0, zf, out=first)
+    kept.open(d_evals, coeffs, cols, q0, zf, out=late)
+    ctx.synchronize()
+    assert torch.equal(first, late)
+    _diff_proof_columns(z, evals, late, cols, [0, 500, 999], [0, 1023, 1024, 2047], z.row_len * 64)
+    kept.free()
+    now.free()
