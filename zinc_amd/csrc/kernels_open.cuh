@@ -58,6 +58,39 @@ struct FieldDev {
     uint64_t inv;
 };
 
+// t (2 FL limbs) = a * b, row by row on 32-bit limbs: x * y + r + carry with 32-bit x, y, r, carry never overflows
+// 64 bits, so every step is ONE v_mad_u64_u32 (which takes a 64-bit addend) plus the carry add.  The same loops on
+// 64-bit limbs with 128-bit intermediates compile to the same number of multiplies, but chained through carry flags
+// with a hazard s_nop behind most of them: 0.49 -> 0.40 ms for round 1 of the sumcheck at 2^24 (its three unreduced
+// products per pair of table entries).
+template <int FL>
+__device__ __forceinline__ void mul_wide(const uint64_t (&a)[FL], const uint64_t (&b)[FL], uint64_t (&t)[2 * FL]) {
+    constexpr int N = 2 * FL;
+    uint32_t x[N], y[N], r[2 * N];
+#pragma unroll
+    for (int i = 0; i < FL; i++) {
+        x[2 * i] = (uint32_t)a[i];
+        x[2 * i + 1] = (uint32_t)(a[i] >> 32);
+        y[2 * i] = (uint32_t)b[i];
+        y[2 * i + 1] = (uint32_t)(b[i] >> 32);
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * N; i++) r[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const uint64_t p = (uint64_t)x[i] * y[j] + r[i + j] + carry;
+            r[i + j] = (uint32_t)p;
+            carry = (uint32_t)(p >> 32);
+        }
+        r[i + N] = carry;
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * FL; i++) t[i] = (uint64_t)r[2 * i] | ((uint64_t)r[2 * i + 1] << 32);
+}
+
 // Montgomery reduction of a 2*FL-limb value t < q*R: returns t * R^-1 mod q, canonical.
 // Same arithmetic as src/field/biginteger.rs:532-560 + the conditional subtraction of
 // src/field/config.rs:68-76 (carry branch for moduli without a spare bit).
@@ -86,6 +119,8 @@ __device__ __forceinline__ void mont_redc(uint64_t (&t)[2 * FL], const FieldDev<
 template <int FL>
 __device__ __forceinline__ void mont_mul(const uint64_t (&a)[FL], const uint64_t (&b)[FL], const FieldDev<FL> &f,
                                          uint64_t (&out)[FL]) {
+    // (the 64-bit-limb product here: with mul_wide's 32-bit rows inlined at every mont_mul the kernels that hold many
+    // of them allocate more registers and lose a wave per SIMD -- sumcheck round 1 0.40 -> 0.79 ms, measured)
     uint64_t t[2 * FL];
 #pragma unroll
     for (int i = 0; i < 2 * FL; i++) t[i] = 0;

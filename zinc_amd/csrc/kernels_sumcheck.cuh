@@ -56,22 +56,7 @@ constexpr int kSumcheckMaxTerms = 8;
 // added up in a (2 FL + 1)-limb accumulator and reduced once per evaluation point and thread.  The canonical residue
 // of the sum is unique, so the message is bit for bit the reference's.  Round 1 of the degree-2 product sumcheck at
 // 2^24: 0.67 -> 0.46 ms (software-pipelined loads on top changed nothing: the 64-bit multiplies bound it).
-template <int FL>
-__device__ __forceinline__ void mul_wide(const uint64_t (&a)[FL], const uint64_t (&b)[FL], uint64_t (&t)[2 * FL]) {
-#pragma unroll
-    for (int i = 0; i < 2 * FL; i++) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < FL; i++) {
-        uint64_t carry = 0;
-#pragma unroll
-        for (int j = 0; j < FL; j++) {
-            const u128 x = (u128)a[i] * b[j] + t[i + j] + carry;
-            t[i + j] = (uint64_t)x;
-            carry = (uint64_t)(x >> 64);
-        }
-        t[i + FL] = carry;
-    }
-}
+// (mul_wide: kernels_open.cuh)
 template <int FL>
 __device__ __forceinline__ void acc_wide_add(uint64_t (&acc)[2 * FL + 1], const uint64_t (&t)[2 * FL]) {
     uint64_t carry = 0;
@@ -154,7 +139,10 @@ __global__ void __launch_bounds__(256) sumcheck_round_kernel(SumcheckRoundArgs<F
     for (int i = 0; i < FL; i++) rr[i] = a.r[i];
 
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + tid; b < a.half; b += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t val[K][FL], step[K][FL];  // the value of MLE k at t = 0 and its increment per unit of t
+        // the values of MLE k at t = 0 and t = 1 (the two table entries); from t = 2 on `val` holds the increment per
+        // unit of t and `nxt` walks: v1 + step, ..  (prover.rs:128-150) -- the same canonical residues as adding the
+        // increment from t = 0, two modular additions per MLE and pair cheaper
+        uint64_t val[K][FL], nxt[K][FL];
 #pragma unroll
         for (int k = 0; k < K; k++) {
             uint64_t v1[FL];
@@ -183,16 +171,9 @@ __global__ void __launch_bounds__(256) sumcheck_round_kernel(SumcheckRoundArgs<F
                 fe_load<FL>(v1, s + FL);
             }
 #pragma unroll
-            for (int i = 0; i < FL; i++) step[k][i] = v1[i];
-            fe_sub<FL>(step[k], val[k], f);
+            for (int i = 0; i < FL; i++) nxt[k][i] = v1[i];
         }
-        // the values at t = 0, 1, 2, ..: v0, v0 + step (= v1), v1 + step, ..  (prover.rs:128-150)
-#pragma unroll
-        for (int e = 0; e <= DEG; e++) {
-            if (e > 0) {
-#pragma unroll
-                for (int k = 0; k < K; k++) fe_add<FL>(val[k], step[k], f);
-            }
+        auto point = [&](const int e, const uint64_t (&val)[K][FL]) {
             uint64_t c[FL], w[2 * FL];  // the point's value = c * val[K - 1], added up unreduced
             if (a.n_terms == 0) {
 #pragma unroll
@@ -244,6 +225,25 @@ __global__ void __launch_bounds__(256) sumcheck_round_kernel(SumcheckRoundArgs<F
             }
             mul_wide<FL>(c, val[K - 1], w);
             acc_wide_add<FL>(wacc[e], w);
+        };
+        point(0, val);
+        if (DEG >= 1) point(1, nxt);
+        if (DEG >= 2) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {  // val <- step = v1 - v0
+                uint64_t d[FL];
+#pragma unroll
+                for (int i = 0; i < FL; i++) d[i] = nxt[k][i];
+                fe_sub<FL>(d, val[k], f);
+#pragma unroll
+                for (int i = 0; i < FL; i++) val[k][i] = d[i];
+            }
+#pragma unroll
+            for (int e = 2; e <= DEG; e++) {
+#pragma unroll
+                for (int k = 0; k < K; k++) fe_add<FL>(nxt[k], val[k], f);
+                point(e, nxt);
+            }
         }
     }
     uint64_t acc[DEG + 1][FL];
