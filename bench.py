@@ -121,6 +121,17 @@ def pmc_entry(kernel, num_vars, mode):
         return None
 
 
+def kernel_sources_sha():
+    """Digest of the kernel sources (the same one tools/pmc_summary.py stores with every pmc_traffic.json entry)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("kernels_commit.cuh", "kernels_open.cuh", "blake3.cuh"):
+        with open(os.path.join(ROOT, "zinc_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def commit_moved_bytes(per, row_len, cw, depth, cols):
     """Bytes the commit kernel really moves per launch (as opposed to SURVEY 8d's full-materialisation figure): the
     witness, 16-byte row entries (the 96 significant bits + sign; Int<4> only on demand), the tree nodes, the
@@ -468,6 +479,8 @@ def main():
             "roofline": {"bound": "valu", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic,
+                         # the committed PMC pass was taken from other kernel sources than the ones this run uses
+                         "traffic_stale": bool(pe) and pe.get("kernel_src_sha") != kernel_sources_sha(),
                          "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(commit_bytes),
                          "moved_bytes_per_launch": moved,
                          "moved_gbs": round(moved / (avg_ms * 1e-3) / 1e9, 1),

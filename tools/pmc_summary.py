@@ -22,6 +22,18 @@ import shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def kernel_sources_sha():
+    """Digest of the kernel sources the counters were taken from: bench.py flags a pmc_traffic.json entry whose digest is
+    not that of the sources it runs with (`traffic_stale`)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("kernels_commit.cuh", "kernels_open.cuh", "blake3.cuh"):
+        with open(os.path.join(ROOT, "zinc_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def find(d, pattern):
     hits = glob.glob(os.path.join(d, "**", pattern), recursive=True)
     return max(hits, key=os.path.getmtime) if hits else None
@@ -121,7 +133,7 @@ def main():
             if cl:
                 traffic[f"{cl[0]}:{a.num_vars}:{cl[1]}"] = {
                     "kernel": k[:120], "num_vars": a.num_vars, "mode": cl[1], "fetch_kib": fk, "write_kib": wk,
-                    "valu_insts": ik, "source": f"profiles/{tag}_pmc.md"}
+                    "valu_insts": ik, "source": f"profiles/{tag}_pmc.md", "kernel_src_sha": kernel_sources_sha()}
         with open(os.path.join(prof, f"{tag}_pmc.md"), "w") as fh:
             fh.write("\n".join(lines) + "\n")
         with open(path, "w") as fh:
