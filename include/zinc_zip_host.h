@@ -43,8 +43,11 @@ int32_t zinc_field_mul(const uint64_t *modulus, uint32_t limbs, const uint64_t *
 int32_t zinc_map_to_field_i64(const uint64_t *modulus, uint32_t limbs, const int64_t *v, size_t n, uint64_t *out);
 int32_t zinc_build_eq_x_r(const uint64_t *modulus, uint32_t limbs, const uint64_t *r, uint32_t nvars, uint64_t *out);
 
-/* shuffle_seeded on the identity (src/zip/utils.rs:139-142; rand 0.9 restated, parity unpinned) */
+/* shuffle_seeded on the identity (src/zip/utils.rs:139-142; rand 0.9 restated, every piece held to a published
+ * vector: tests/golden/rand_vectors.json) */
 void zinc_shuffle_seeded_perm(uint64_t seed, uint32_t len, uint32_t *perm);
+/* known-answer hook: the first n_words little-endian words rand_core::SeedableRng::seed_from_u64 expands `seed` to */
+void zinc_kat_seed_from_u64(uint64_t seed, uint32_t *words, uint32_t n_words);
 
 /* RaaCode::new (src/zip/code_raa.rs:35-86).  transcript == NULL uses MockTranscript (seeds 1, 2). */
 typedef struct {

@@ -605,9 +605,10 @@ int orc_build_eq_x_r(const orc_field *f, const uint64_t *r, uint32_t nvars, uint
 /*   PCG32 step + XSH-RR      O'Neill's pcg32 demo (seed 42, stream 54)      */
 /*   IncreasingUniform shuffle + Canon's-method random_range                 */
 /*                            rand's value_stability_slice (Pcg32(414))      */
-/* NOT pinned by any vector: the eight lines of rand_core's seed_from_u64    */
-/* that chain these (advance-then-output PCG32 with the fixed increment,     */
-/* 4 bytes little-endian per step).                                          */
+/*   rand_core seed_from_u64 (advance-then-output PCG32 with the fixed       */
+/*   increment, 4 bytes little-endian per step)                              */
+/*                            rand_pcg's test_lcg64xsh32_construction:       */
+/*                            Lcg64Xsh32::seed_from_u64(0).next_u64()        */
 /* ======================================================================== */
 typedef struct {
     uint32_t key[8];
@@ -775,7 +776,7 @@ void orc_kat_shuffle_pcg32(uint64_t state, uint64_t stream, uint32_t len, uint32
     pcg32_new(&g, state, stream);
     shuffle_perm(pcg32_next_u32, &g, len, perm);
 }
-/* the 32-byte seed seed_from_u64 expands `state` to (the unpinned link) */
+/* the 32-byte seed seed_from_u64 expands `state` to (its first 16 bytes seed rand_pcg's construction vector) */
 void orc_kat_seed_from_u64(uint64_t state, uint32_t key_out[8]) {
     chacha12_rng g;
     chacha12_seed_from_u64(&g, state);

@@ -25,9 +25,9 @@
  *    piece by published vectors (tests/golden/rand_vectors.json): the ChaCha12
  *    block, StdRng's word/counter layout (rand's test_stdrng_construction),
  *    PCG32 (O'Neill's demo), the IncreasingUniform shuffle with Canon's-method
- *    random_range (rand's value_stability_slice).  The one link WITHOUT a
- *    vector is rand_core's seed_from_u64 (PCG32 expansion of the u64 seed):
- *    that link stays "parity unpinned".  The product ABI takes explicit
+ *    random_range (rand's value_stability_slice), and rand_core's
+ *    seed_from_u64 (PCG32 expansion of the u64 seed: rand_pcg's
+ *    test_lcg64xsh32_construction).  The product ABI takes explicit
  *    permutation tables, so nothing on the GPU depends on any of this.
  *  - The reference itself (Rust) cannot be built in this image (no cargo/rustc,
  *    no vendored crates), so there is no oracle/_ref.

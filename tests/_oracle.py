@@ -52,6 +52,12 @@ def build(force=False):
     process that has initialised the GPU must never do on the GPU boxes: call it FIRST (pytest_configure, the top of
     bench.main(), smoke() and the tools do), never lazily."""
     if force or _stale():
+        # Under `rocprofv3 ... -- python3 tool.py` the profiler's preloaded library has initialised the GPU before this
+        # line runs: then even this early call must not fork + exec.
+        preload = os.environ.get("LD_PRELOAD", "")
+        if "rocprof" in preload or any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ):
+            raise RuntimeError(f"{_LIB_PATH} is missing or stale and this process runs under a profiler: "
+                               "run `make -C oracle` first (a GPU-initialised process must not fork + exec)")
         subprocess.run(["make", "-B", "-C", ORACLE_DIR], check=True, capture_output=True)
     return _LIB_PATH
 

@@ -309,6 +309,35 @@ def test_open_stream_pieces_concatenate_to_the_proof(cabi, num_vars, chunk):
     assert com.open(evals, cf, cols, q0, cabi.make_field(BENCH_MODULUS, 4)).tobytes() == proof_o.tobytes()
 
 
+@pytest.mark.parametrize("how", ["hinted", "commit_open"])
+def test_open_stream_on_a_packed_handle(cabi, how):
+    """A packed hinted handle (zip_commit_hinted / zip_commit_open(out=&h), the default from codeword 512 up) opened
+    through zip_open_stream in SEVERAL column groups: group g > 0 must use the ranks of ITS openings (round-2 advisor
+    finding: every group read the ranks of group 0)."""
+    num_vars = 16  # 256 x 256, cw = 512: the smallest geometry with packed openings
+    z = orc.Zip(num_vars)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    evals = _witness(num_vars, seed=21)
+    point = orc.point_to_field(f, np.arange(num_vars, dtype=np.int64) + 2)
+    rows_o, layers_o, _ = z.commit(evals)
+    proof_o, cols, coeffs = z.open(f, evals, rows_o, layers_o, point, orc.new_transcript())
+    lr = z.num_rows.bit_length() - 1
+    q0 = orc.build_eq_x_r(f, point[num_vars - lr:])
+    ctx = _ctx(cabi, z)
+    if how == "hinted":
+        com, _ = ctx.commit(evals, hint_cols=cols)
+    else:
+        proof1, _, com = ctx.commit_open(evals, coeffs, cols, q0, zf, keep=True)
+        assert np.asarray(proof1).tobytes() == proof_o.tobytes()
+    per_col = z.num_rows * (32 + 8 + 32 * z.depth)
+    for chunk in (7 * per_col, per_col, 0):  # 143 groups of 7 columns; one column per group; one group
+        pieces = []
+        com.open_stream(evals, coeffs, cols, q0, zf, lambda mv: pieces.append(bytes(mv)) and None, chunk_bytes=chunk)
+        assert b"".join(pieces) == proof_o.tobytes(), chunk
+    com.free()
+
+
 def test_pipelined_gather_recovers_from_a_timed_out_wait(cabi, monkeypatch):
     """The gather of a chunk is gated on a counter of the still running commit kernel; when that wait
     gives up (kernel dispatch serialised by a profiler, say) the gather is redone after the commit."""
@@ -491,6 +520,43 @@ def test_jobs_in_flight_produce_the_same_proofs(cabi, num_vars):
         assert np.array_equal(got_roots[i], want[i][1]), i
         bad = np.flatnonzero(outs[i].cpu().numpy() != want[i][0])
         assert bad.size == 0, f"job {i}: {bad.size} proof bytes differ, first at {bad[:8]}"
+
+
+def test_two_jobs_in_flight_recover_from_timed_out_waits(cabi, monkeypatch):
+    """Both jobs' pipeline waits give up (ZIP_HIP_FORCE_WAIT_TIMEOUT): the first zip_job_wait drains the streams and
+    clears the flag, the SECOND job must still re-gather (round-2 advisor finding: it returned a proof whose gathers
+    had run before the commit kernel published their rows)."""
+    torch = pytest.importorskip("torch")
+    num_vars = 22
+    z = orc.Zip(num_vars)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    point = orc.point_to_field(f, np.arange(-7, num_vars - 7, dtype=np.int64))
+    lr = z.num_rows.bit_length() - 1
+    q0 = orc.build_eq_x_r(f, point[num_vars - lr:])
+    rng = np.random.default_rng(6)
+    coeffs = rng.integers(-(1 << 62), 1 << 62, size=z.num_rows, dtype=np.int64)
+    cols = rng.integers(0, z.codeword_len, size=200, dtype=np.uint32)
+    monkeypatch.setenv("ZIP_HIP_CHUNKS", "4")
+    ctx = _ctx(cabi, z)
+    witnesses = [torch.from_numpy(_witness(num_vars, seed=60 + i)).cuda() for i in range(2)]
+    want = [ctx.commit_open(w, coeffs, cols, q0, zf)[0] for w in witnesses]
+    outs = [torch.full((want[0].size,), 0x5A, dtype=torch.uint8, device="cuda") for _ in witnesses]
+    torch.cuda.synchronize()
+    monkeypatch.setenv("ZIP_HIP_FORCE_WAIT_TIMEOUT", "200")  # 2 us: the gathers run long before their rows exist
+    jobs = [ctx.commit_open_begin(witnesses[i], coeffs, cols, q0, zf, outs[i]) for i in range(2)]
+    monkeypatch.delenv("ZIP_HIP_FORCE_WAIT_TIMEOUT")
+    for j in jobs:
+        j.wait()
+    ctx.synchronize()
+    for i in range(2):
+        bad = np.flatnonzero(outs[i].cpu().numpy() != np.asarray(want[i]))
+        assert bad.size == 0, f"job {i}: {bad.size} proof bytes differ, first at {bad[:8]}"
+    # and the ctx is back to normal: a plain job afterwards
+    j = ctx.commit_open_begin(witnesses[0], coeffs, cols, q0, zf, outs[1])
+    j.wait()
+    ctx.synchronize()
+    assert np.array_equal(outs[1].cpu().numpy(), np.asarray(want[0]))
 
 
 @pytest.mark.parametrize("num_vars", [12, 16, 18])

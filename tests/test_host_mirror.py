@@ -92,7 +92,7 @@ def test_field_constants_map_to_field_and_eq(modulus, fl):
 
 def test_shuffle_seeded_three_implementations_agree():
     """C++ host mirror == Python mirror == oracle restatement.  The oracle's pieces are pinned by published vectors
-    (tests/test_oracle_kats.py, tests/golden/rand_vectors.json) except rand_core's seed_from_u64; agreement on whole
+    (tests/test_oracle_kats.py, tests/golden/rand_vectors.json), rand_core's seed_from_u64 included; agreement on whole
     permutations for many (seed, length) extends those pins to the other two restatements."""
     from zinc_amd.perm import shuffle_seeded_perm as py_perm
     for seed, n in ((1, 512), (2, 8192), (12345, 10), (2**63 + 11, 64), (7, 1), (9, 2), (3, 16384), (0, 13)):
@@ -125,6 +125,28 @@ def test_python_permutation_module_against_the_published_vectors():
     sv = v["shuffle_value_stability"]
     got = perm.shuffle_perm_with(perm.Pcg32(sv["pcg32_state"], int(sv["pcg32_stream"])), sv["len"])
     assert [int(x) for x in got] == sv["shuffled"]
+    # seed_from_u64: rand_pcg's construction vector, through this module's own expansion
+    ps = v["pcg32_seed_from_u64"]
+    assert perm.Pcg32.from_seed(ps["from_seed_bytes"]).next_u64() == int(ps["from_seed_next_u64"])
+    seed16 = b"".join(w.to_bytes(4, "little") for w in perm.seed_from_u64_words(ps["seed_from_u64_seed"], 4))
+    assert perm.Pcg32.from_seed(seed16).next_u64() == int(ps["seed_from_u64_next_u64"])
+    assert perm.ChaCha12Rng(seed_u64=5).key == perm.seed_from_u64_words(5, 8)
+
+
+def test_cpp_mirror_seed_expansion_against_rand_pcgs_vector():
+    """The C++ host mirror's seed_from_u64 (zinc_kat_seed_from_u64) against the same published vector."""
+    import json
+    import os
+
+    from zinc_amd import perm
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "rand_vectors.json")) as fh:
+        ps = json.load(fh)["pcg32_seed_from_u64"]
+    words = pcs.kat_seed_from_u64(ps["seed_from_u64_seed"], 4)
+    seed16 = b"".join(w.to_bytes(4, "little") for w in words)
+    assert perm.Pcg32.from_seed(seed16).next_u64() == int(ps["seed_from_u64_next_u64"])
+    for seed in (1, 2, 0xDEADBEEF, 2**64 - 1):
+        assert pcs.kat_seed_from_u64(seed, 8) == perm.seed_from_u64_words(seed, 8) == orc.kat_seed_from_u64(seed)
 
 
 def test_raa_code_new_geometry_and_seeds():

@@ -321,10 +321,35 @@ def test_shuffle_algorithm_matches_rands_value_stability_vector():
     assert list(got) == v["shuffled"]
 
 
+def _pcg32_from_seed_next_u64(seed16):
+    """rand_pcg::Lcg64Xsh32::from_seed(seed).next_u64(), in Python integers: state = LE u64 of bytes 0..8, increment =
+    LE u64 of bytes 8..16 | 1, `state += inc; step()`; next_u64 = two XSH-RR outputs, low word first."""
+    M, MUL = (1 << 64) - 1, 6364136223846793005
+    inc = int.from_bytes(bytes(seed16[8:16]), "little") | 1
+    state = ((int.from_bytes(bytes(seed16[:8]), "little") + inc) * MUL + inc) & M
+    words = []
+    for _ in range(2):
+        xs, rot = (((state >> 18) ^ state) >> 27) & 0xFFFFFFFF, state >> 59
+        words.append(((xs >> rot) | (xs << ((32 - rot) & 31))) & 0xFFFFFFFF)
+        state = (state * MUL + inc) & M
+    return words[0] | (words[1] << 32)
+
+
+def test_seed_from_u64_matches_rand_pcgs_construction_vector():
+    """rand_core::SeedableRng::seed_from_u64 -- the link zip/utils.rs:139-142 goes through and the last one that had no
+    external anchor -- held to rand_pcg's own test_lcg64xsh32_construction: `Lcg64Xsh32::seed_from_u64(0).next_u64()`.
+    The provided method is generic: Pcg32 takes the first 16 bytes of the expansion StdRng takes 32 of."""
+    v = _rand_vectors()["pcg32_seed_from_u64"]
+    assert _pcg32_from_seed_next_u64(v["from_seed_bytes"]) == int(v["from_seed_next_u64"])  # pins from_seed / next_u64 above
+    words = orc.kat_seed_from_u64(v["seed_from_u64_seed"])  # the oracle's expansion (8 words; Pcg32 uses 4)
+    seed16 = b"".join(w.to_bytes(4, "little") for w in words[:4])
+    assert _pcg32_from_seed_next_u64(seed16) == int(v["seed_from_u64_next_u64"])
+
+
 def test_seed_from_u64_link_is_the_documented_pcg32_expansion():
-    """The one link without a published vector: what is checked here is only that the oracle's seed expansion IS
-    the procedure its header describes (PCG32 steps with rand_core's increment, output of the NEW state), written a
-    second time in Python; `orc_shuffle_seeded_perm` = that seed -> ChaCha12 -> the pinned shuffle."""
+    """The oracle's seed expansion IS the procedure its header describes (PCG32 steps with rand_core's increment, output
+    of the NEW state), written a second time in Python, for more seeds than the published vector covers;
+    `orc_shuffle_seeded_perm` = that seed -> ChaCha12 -> the pinned shuffle."""
     M = (1 << 64) - 1
     for seed in (0, 1, 2, 0xDEADBEEF, M):
         state, want = seed, []

@@ -37,8 +37,8 @@ int main(int argc, char **argv) {
     for (auto &x : ev) x = (int64_t)(((uint64_t)g() << 32) | g());
     CommitArgs a{};
     int64_t *evd; uint32_t *p1d, *p2d, *flag;
-    unsigned long long *stamps_h; CK(hipHostMalloc(&stamps_h, (64 * G + 4 * G + 64) * 8));
-    for (size_t i = 0; i < 64 * G + 4 * G + 64; i++) stamps_h[i] = 0;
+    unsigned long long *stamps_h; CK(hipHostMalloc(&stamps_h, (size_t)kStampRec * G * 8));
+    for (size_t i = 0; i < (size_t)kStampRec * G; i++) stamps_h[i] = 0;
     uint4 *ca, *cb; const size_t cn = (size_t)1 << 26; CK(hipMalloc(&ca, cn * 16)); CK(hipMalloc(&cb, cn * 16)); CK(hipMemset(ca, 1, cn * 16));
     CK(hipMalloc(&evd, ev.size() * 8)); CK(hipMalloc(&p1d, cw * 4)); CK(hipMalloc(&p2d, cw * 4)); CK(hipMalloc(&flag, 64));
     CK(hipMalloc(&a.rows, (size_t)R * cw * 32)); CK(hipMalloc(&a.layers, (size_t)R * 2 * cw * 32)); CK(hipMalloc(&a.chunk_done, 256));
@@ -67,7 +67,7 @@ int main(int argc, char **argv) {
             CK(hipEventElapsedTime(&ms, e0, e1));
         }
         double pa = 0, pb = 0, pc = 0;
-        for (uint32_t w = 0; w < G; w++) { pa += stamps_h[64 * G + 4 * w]; pb += stamps_h[64 * G + 4 * w + 1]; pc += stamps_h[64 * G + 4 * w + 2]; }
+        for (uint32_t w = 0; w < G; w++) { pa += stamps_h[(size_t)kStampRec * w + 3]; pb += stamps_h[(size_t)kStampRec * w + 4]; pc += stamps_h[(size_t)kStampRec * w + 5]; }
         printf("%-28s commit %.3f ms | per-WG avg: encode phases %.1f us, hash phase %.1f us, chunk end+stage %.1f us\n", names[mode], ms,
                pa / G / 100.0, pb / G / 100.0, pc / G / 100.0);
     }

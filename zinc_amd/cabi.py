@@ -53,6 +53,28 @@ class Job:
         self._ctx._check(rc, "zip_job_wait")
         return roots
 
+    def close(self):
+        """Collects a job nobody waited for (an exception between begin and wait): frees its slot of the ctx and keeps
+        the buffers alive until the GPU is done with them."""
+        if self._h is not None:
+            h, self._h = self._h, None
+            try:
+                lib().zip_job_wait(h, None)
+            finally:
+                self._keep = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
 
 class ZipError(RuntimeError):
     def __init__(self, code, what, detail=""):

@@ -24,6 +24,15 @@ namespace zipk {
 typedef __int128 i128;
 typedef unsigned __int128 u128;
 
+#ifdef ZIPK_DEBUG_STAMPS
+constexpr uint32_t kStampRec = 64;
+__device__ __forceinline__ unsigned long long stamp_hw_id() {
+    // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, 0, 4) / hwreg(HW_REG_HW_ID = 4, 0, 32)
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20), hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    return (unsigned long long)xcc | ((unsigned long long)hw << 8);
+}
+#endif
+
 struct CommitArgs {
     const int64_t *evals;
     const uint32_t *perm1;
@@ -55,7 +64,10 @@ struct CommitArgs {
     // of bench.py is priced at that clock, not at a datasheet figure)
     unsigned long long *clock;
 #ifdef ZIPK_DEBUG_STAMPS
-    unsigned long long *stamps;  // tools/ubench_pipeline.hip: [chunk][workgroup] wall-clock of each arrival
+    // tools/wg_spread.py, tools/ubench_pipeline.hip: kStampRec words per workgroup (100 MHz wall clock):
+    // [0] start [1] end [2] XCC id | HW_ID << 8 [3..5] time in the scan passes / hash phase / chunk ends [6] rows done
+    // [8 + i] end of the workgroup's i-th row (i < kStampRec - 8)
+    unsigned long long *stamps;
 #endif
 };
 
@@ -400,9 +412,6 @@ __device__ __forceinline__ void finish_chunk(const CommitArgs &a, uint32_t first
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back has landed before the count moves
 #endif
             __hip_atomic_fetch_add(&a.chunk_done[cc.index], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef ZIPK_DEBUG_STAMPS
-            a.stamps[cc.index * gridDim.x + blockIdx.x] = wall_clock64();
-#endif
         }
     }
 }
@@ -499,6 +508,10 @@ __global__ void __launch_bounds__(1024, MODE != kStoreAll ? 4 : 5) raa_commit_ke
 
 #ifdef ZIPK_DEBUG_STAMPS
     unsigned long long ph_a = 0, ph_b = 0, ph_c = 0, ph_t;
+    if (tid0 == 0 && a.stamps) {
+        a.stamps[(size_t)kStampRec * blockIdx.x] = wall_clock64();
+        a.stamps[(size_t)kStampRec * blockIdx.x + 2] = stamp_hw_id();
+    }
 #define ZIPK_PH(acc) do { const unsigned long long now_ = wall_clock64(); acc += now_ - ph_t; ph_t = now_; } while (0)
 #else
 #define ZIPK_PH(acc) do { } while (0)
@@ -628,12 +641,16 @@ __global__ void __launch_bounds__(1024, MODE != kStoreAll ? 4 : 5) raa_commit_ke
             cc.advance(round);
         }
         ZIPK_PH(ph_c);
+#ifdef ZIPK_DEBUG_STAMPS
+        if (tid0 == 0 && a.stamps && round < kStampRec - 8) a.stamps[(size_t)kStampRec * blockIdx.x + 8 + round] = ph_t;
+#endif
     }
     stamp_clock(a, 1);
 #ifdef ZIPK_DEBUG_STAMPS
     if (tid0 == 0 && a.stamps) {
-        unsigned long long *o = a.stamps + 64 * gridDim.x + 4 * blockIdx.x;
-        o[0] = ph_a; o[1] = ph_b; o[2] = ph_c;
+        unsigned long long *o = a.stamps + (size_t)kStampRec * blockIdx.x;
+        o[1] = wall_clock64();
+        o[3] = ph_a; o[4] = ph_b; o[5] = ph_c; o[6] = round;
     }
 #endif
 }

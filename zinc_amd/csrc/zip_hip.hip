@@ -248,6 +248,11 @@ static long spin_budget_us() {
     static const long us = getenv("ZIP_HIP_SPIN_US") ? atol(getenv("ZIP_HIP_SPIN_US")) : 4000;
     return us;
 }
+// hipErrorNotReady may be left behind as the thread's "last error" by a poll: the launch checks must not find it --
+// but a GENUINE pending error (a failed launch somebody checks later) must stay where it is.
+static inline void clear_not_ready() {
+    if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();
+}
 template <class Query>
 static inline bool spin_until_done(Query query, hipError_t *result) {
     const long budget = spin_budget_us();
@@ -255,11 +260,10 @@ static inline bool spin_until_done(Query query, hipError_t *result) {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned it = 0;; it++) {
         const hipError_t e = query();
-        // (hipErrorNotReady may be left behind as the thread's "last error": the launch checks must not find it)
-        if (e != hipErrorNotReady) { if (it) (void)hipGetLastError(); *result = e; return true; }
+        if (e != hipErrorNotReady) { if (it) clear_not_ready(); *result = e; return true; }
         if ((it & 15u) == 15u &&
             std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > budget) {
-            (void)hipGetLastError();
+            clear_not_ready();
             return false;
         }
     }
@@ -1172,8 +1176,10 @@ void gather_order(const uint32_t *cols, uint32_t n_cols, uint32_t *order) {
 }
 
 // cols_dv: DEVICE pointer (already staged).  Emits the openings of rows [row_lo, row_hi).
+// `first_opening`: cols_dv points at opening number first_opening of the list the handle was hinted with (a packed
+// handle's rank table is indexed by the opening; zip_open_stream emits the list in groups).
 int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d,
-                         uint32_t row_lo, uint32_t row_hi) {
+                         uint32_t row_lo, uint32_t row_hi, uint32_t first_opening = 0) {
     zip_ctx *ctx = c->ctx;
     if (n_cols == 0 || row_hi <= row_lo) return ZIP_OK;
     OpenColsArgs a{};
@@ -1189,7 +1195,7 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
         a.pk_off0 = c->pk_off[0];
         a.pk_off1 = c->pk_off[1];
         a.pk_off2 = c->pk_off[2];
-        a.pk_rank = c->rank_d;
+        a.pk_rank = c->rank_d + (size_t)first_opening * 4;
     }
     a.out = out_d;
     a.num_rows = ctx->rows_local;
@@ -1254,13 +1260,16 @@ int32_t run_open_columns_pipelined(zip_commitment *c, const uint32_t *cols_dv, u
     }
     if (c->zeroed) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, c->zeroed, 0));
     // test hook: an unreachable target and a 1 ms limit exercise the recovery path of a timed-out wait
-    const bool force_timeout = getenv("ZIP_HIP_FORCE_WAIT_TIMEOUT") != nullptr;
+    // (a value > 1 is the limit in ticks of the 100 MHz clock: short enough and the gathers run BEFORE their rows exist)
+    const char *force_env = getenv("ZIP_HIP_FORCE_WAIT_TIMEOUT");
+    const bool force_timeout = force_env != nullptr;
+    const unsigned long long force_ticks = (force_env && atoll(force_env) > 1) ? (unsigned long long)atoll(force_env) : 100000ull;
     for (size_t k = 0; k + 1 < c->bounds.size(); k++) {
         {
             LaunchTimer t(ctx, "wait_counter_kernel");
             hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, ctx->stream, c->chunk_done + k,
                                force_timeout ? 0xFFFFFFFFu : c->expected[k], 0u, ctx->timeout_flag_d,
-                               force_timeout ? 100000ull : 25000000ull /* 0.25 s at 100 MHz */);
+                               force_timeout ? force_ticks : 25000000ull /* 0.25 s at 100 MHz */);
             HIP_TRY(ctx, hipGetLastError());
         }
         int32_t rc = run_open_columns(c, cols_dv, n_cols, out_d, c->bounds[k], c->bounds[k + 1]);
@@ -1277,11 +1286,14 @@ size_t column_bytes(const zip_ctx *ctx) {
 // kernel could not run -- which happens when something serialises kernel dispatch across streams
 // (rocprofv3 counter collection does, and may run the waiter first).  The gathers behind that wait
 // read rows that did not exist yet, so the whole gather is redone once the commit has really finished.
-int32_t recover_gather_timeout(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d) {
+// `force`: redo it although the flag is down -- another job's recovery has already drained the stream and cleared the
+// flag, and THIS job's gathers may have run behind a timed-out wait as well (zip_job_wait, two jobs in flight).
+int32_t recover_gather_timeout(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d, bool force = false) {
     zip_ctx *ctx = c->ctx;
     HIP_TRY(ctx, stream_wait(ctx->stream));
-    if (!(ctx->timeout_flag_h && *ctx->timeout_flag_h)) return ZIP_OK;
-    *ctx->timeout_flag_h = 0;
+    const bool timed_out = ctx->timeout_flag_h && *ctx->timeout_flag_h;
+    if (!timed_out && !force) return ZIP_OK;
+    if (ctx->timeout_flag_h) *ctx->timeout_flag_h = 0;
     int32_t rc = wait_ready(c, ctx->stream);
     if (rc) return rc;
     if ((rc = run_open_columns(c, cols_dv, n_cols, out_d, 0, ctx->rows_local))) return rc;
@@ -1873,6 +1885,20 @@ int32_t zip_ctx_synchronize(zip_ctx *ctx) {
 
 void *zip_ctx_stream(zip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+#ifdef ZIPK_DEBUG_STAMPS
+// Debug build only (tools/wg_spread.py): one pinned, host-mapped block every commit kernel stamps into.
+constexpr size_t kDebugStampWords = (size_t)kStampRec * 2048;
+static unsigned long long *debug_stamps_buffer() {
+    static unsigned long long *buf = nullptr;
+    if (!buf && hipHostMalloc((void **)&buf, kDebugStampWords * 8, hipHostMallocDefault) == hipSuccess) memset(buf, 0, kDebugStampWords * 8);
+    return buf;
+}
+extern "C" unsigned long long *zip_debug_stamps(uint32_t *words_per_wg) {
+    if (words_per_wg) *words_per_wg = kStampRec;
+    return debug_stamps_buffer();
+}
+#endif
+
 static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
                            int32_t with_merkle, const uint32_t *hint_cols, uint32_t n_hint, uint8_t *roots_out,
                            zip_commitment **out) {
@@ -1978,6 +2004,9 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
         a.chunk_ends = chunk_ends;
         a.roots = c->roots;
         a.clock = ctx->profiling ? ctx->clock_d : nullptr;
+#ifdef ZIPK_DEBUG_STAMPS
+        a.stamps = debug_stamps_buffer();
+#endif
         hipError_t e = hipSuccess;
         if (with_merkle && hint_cols && commit_supports_hint(cw)) {
             // the hint bitmaps (CommitArgs.need): V | N0 | N1 | N2, see kernels_commit.cuh
@@ -2495,8 +2524,8 @@ static int32_t open_enqueue(zip_commitment *c, const int64_t *evals_d, const int
     return ZIP_OK;
 }
 // synchronises: the small host inputs (coeffs, cols, q0) have been consumed, every launch has run
-static int32_t open_finish(zip_commitment *c, OpenState &st) {
-    const int32_t rc = recover_gather_timeout(c, st.cols_dv, st.n_cols, st.openings_d);
+static int32_t open_finish(zip_commitment *c, OpenState &st, bool force_regather = false) {
+    const int32_t rc = recover_gather_timeout(c, st.cols_dv, st.n_cols, st.openings_d, force_regather);
     c->gather_order = nullptr;  // the table lives in st.small
     return rc;
 }
@@ -2659,12 +2688,16 @@ int32_t zip_job_wait(zip_job *j, uint8_t *roots_out) {
     hipError_t e = event_wait(j->finished);  // NOT the stream: the next job may already be queued behind this one
     if (e != hipSuccess) rc = fail(ctx, ZIP_ERR_HIP, "job failed: %s", hipGetErrorString(e));
     if (!rc && ((ctx->timeout_flag_h && *ctx->timeout_flag_h) || ctx->job_redo)) {
-        // a pipeline wait gave up (counter collection serialises the streams): everything in flight is redone
+        // a pipeline wait gave up (counter collection serialises the streams): everything in flight is redone.  The
+        // first job to notice drains the streams and clears the flag; the job that was queued behind it cannot tell
+        // any more whether ITS waits gave up too, so it re-gathers unconditionally (job_redo).
+        const bool forced = ctx->job_redo;
         ctx->job_redo = ctx->job_busy[0] && ctx->job_busy[1];
-        rc = open_finish(j->c, *j->st);  // (synchronises the streams)
+        rc = open_finish(j->c, *j->st, forced);  // (synchronises the streams)
     }
     if (!rc && roots_out) {
-        if (!(rc = wait_ready(j->c, ctx->stream))) rc = deliver(ctx, roots_out, ZIP_MEM_HOST, j->c->roots, j->c->roots_bytes);
+        // on s_upper, ordered after this job's commit only: the main stream may already hold the NEXT job's whole open
+        if (!(rc = wait_ready(j->c, ctx->s_upper))) rc = copy_d2h_bounced(ctx, roots_out, j->c->roots, j->c->roots_bytes, ctx->s_upper);
     }
     // everything of this job on the main and the fold stream has run: nothing to drain, nothing to wait for
     const std::string keep = ctx->last_error;
@@ -3237,7 +3270,7 @@ int32_t zip_open_stream(zip_commitment *c, const int64_t *evals, zip_mem_kind ev
         const int b = (int)(g & 1);
         const uint32_t first = (uint32_t)(g * group), cnt = (uint32_t)std::min(group, (size_t)n_cols - first);
         if (g >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, copied[b], 0));  // dev[b] has left the device
-        int32_t r = run_open_columns(c, cols_d + first, cnt, dev[b], 0, ctx->rows_local);
+        int32_t r = run_open_columns(c, cols_d + first, cnt, dev[b], 0, ctx->rows_local, first);
         if (r) return r;
         HIP_TRY(ctx, hipEventRecord(gathered[b], ctx->stream));
         return ZIP_OK;

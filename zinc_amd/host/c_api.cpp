@@ -106,6 +106,8 @@ void zinc_shuffle_seeded_perm(uint64_t seed, uint32_t len, uint32_t *perm) {
     for (uint32_t i = 0; i < len; i++) perm[i] = p[i];
 }
 
+void zinc_kat_seed_from_u64(uint64_t seed, uint32_t *words, uint32_t n_words) { kat_seed_from_u64(seed, words, n_words); }
+
 int32_t zinc_raa_code_new(uint64_t poly_size, zinc_transcript *transcript, zinc_raa_code *out) {
     if (!out) return ZINC_ERR_NULL;
     return guarded([&] {

@@ -532,20 +532,23 @@ namespace zip {
 
 // ============================================================================ shuffle_seeded
 // rand 0.9.2: StdRng = ChaCha12, seed_from_u64 = PCG32 expansion, SliceRandom::shuffle =
-// IncreasingUniform Fisher-Yates with Canon's-method random_range.  PARITY UNPINNED (see perm.py).
+// IncreasingUniform Fisher-Yates with Canon's-method random_range.  Every piece pinned by published vectors
+// (tests/golden/rand_vectors.json; the seed expansion directly through zinc_kat_seed_from_u64).
 namespace {
 struct ChaCha12 {
     uint32_t key[8];
     uint64_t counter = 0;
     uint32_t buf[16];
     int idx = 16;
-    explicit ChaCha12(uint64_t state) {
-        for (int i = 0; i < 8; i++) {
+    // rand_core::SeedableRng::seed_from_u64: PCG32 steps, the state advanced before each output
+    static void seed_words(uint64_t state, uint32_t *out, int n) {
+        for (int i = 0; i < n; i++) {
             state = state * 6364136223846793005ULL + 11634580027462260723ULL;
             const uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27), rot = (uint32_t)(state >> 59);
-            key[i] = (xs >> rot) | (xs << ((32 - rot) & 31));
+            out[i] = (xs >> rot) | (xs << ((32 - rot) & 31));
         }
     }
+    explicit ChaCha12(uint64_t state) { seed_words(state, key, 8); }
     static inline uint32_t rotl(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
     void refill() {
         uint32_t s[16] = {0x61707865, 0x3320646e, 0x79622d32, 0x6b206574}, x[16];
@@ -584,6 +587,8 @@ struct ChaCha12 {
     }
 };
 }  // namespace
+
+void kat_seed_from_u64(uint64_t seed, uint32_t *words, uint32_t n_words) { ChaCha12::seed_words(seed, words, (int)n_words); }
 
 std::vector<uint32_t> shuffle_seeded_perm(uint64_t seed, uint32_t len) {
     std::vector<uint32_t> perm(len);

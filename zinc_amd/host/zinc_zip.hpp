@@ -141,6 +141,8 @@ namespace zip {
 
 // shuffle_seeded applied to the identity: shuffle_seeded(x, seed)[j] == x[perm[j]].
 std::vector<uint32_t> shuffle_seeded_perm(uint64_t seed, uint32_t len);
+// the seed bytes rand_core's seed_from_u64 expands `seed` to, as little-endian words (known-answer hook)
+void kat_seed_from_u64(uint64_t seed, uint32_t *words, uint32_t n_words);
 
 // LinearCodeSpec / DefaultLinearCodeSpec (src/zip/code.rs:217-242)
 struct LinearCodeSpec {

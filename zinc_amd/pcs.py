@@ -16,7 +16,7 @@ EXPORTED_SYMBOLS = (
     "zinc_last_error", "zinc_transcript_new", "zinc_transcript_free", "zinc_transcript_absorb",
     "zinc_transcript_get_u64", "zinc_transcript_get_integer_challenges", "zinc_transcript_get_challenge",
     "zinc_field_constants", "zinc_field_mul", "zinc_map_to_field_i64", "zinc_build_eq_x_r",
-    "zinc_shuffle_seeded_perm", "zinc_raa_code_new", "zinc_zip_setup", "zinc_zip_params_free",
+    "zinc_shuffle_seeded_perm", "zinc_kat_seed_from_u64", "zinc_raa_code_new", "zinc_zip_setup", "zinc_zip_params_free",
     "zinc_zip_params_geometry", "zinc_zip_commit", "zinc_zip_data_free", "zinc_pcs_transcript_new",
     "zinc_pcs_transcript_free", "zinc_pcs_transcript_len", "zinc_pcs_transcript_copy",
     "zinc_pcs_transcript_probe", "zinc_zip_open", "zinc_pcs_transcript_from_proof", "zinc_pcs_transcript_position",
@@ -77,6 +77,8 @@ def lib():
         L.zinc_build_eq_x_r.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp]
         L.zinc_shuffle_seeded_perm.argtypes = [C.c_uint64, C.c_uint32, vp]
         L.zinc_shuffle_seeded_perm.restype = None
+        L.zinc_kat_seed_from_u64.argtypes = [C.c_uint64, vp, C.c_uint32]
+        L.zinc_kat_seed_from_u64.restype = None
         L.zinc_raa_code_new.argtypes = [C.c_uint64, vp, C.POINTER(RaaCodeStruct)]
         L.zinc_zip_setup.argtypes = [C.c_uint64, C.POINTER(RaaCodeStruct), C.c_int32, C.POINTER(vp)]
         L.zinc_zip_params_free.argtypes = [vp]
@@ -206,6 +208,12 @@ class KeccakTranscript:
         out = np.zeros(field.limbs, np.uint64)
         _check(lib().zinc_transcript_get_challenge(self._h, field._m.ctypes.data, field.limbs, out.ctypes.data))
         return out
+
+
+def kat_seed_from_u64(seed: int, n_words: int):
+    out = np.zeros(n_words, np.uint32)
+    lib().zinc_kat_seed_from_u64(seed, out.ctypes.data, n_words)
+    return [int(x) for x in out]
 
 
 def shuffle_seeded_perm(seed: int, length: int) -> np.ndarray:

@@ -7,9 +7,9 @@ then `SliceRandom::shuffle`, applied to the identity so that
 rand 0.9.2 / rand_chacha are not vendored in the reference and no reference test pins a
 permutation, so this restates the crates' published algorithm (PCG32 seed expansion ->
 ChaCha12 block RNG -> IncreasingUniform Fisher-Yates with Canon's-method `random_range`).
-Every piece except the seed expansion is pinned by a published vector
-(tests/golden/rand_vectors.json, tests/test_host_mirror.py); `seed_from_u64` itself is the
-one link that stays parity-unpinned.  In the Rust integration the shim calls the real
+Every piece is pinned by a published vector (tests/golden/rand_vectors.json,
+tests/test_host_mirror.py) -- since round 3 also `seed_from_u64`, by rand_pcg's own
+construction vector (`Lcg64Xsh32::seed_from_u64(0).next_u64()`).  In the Rust integration the shim calls the real
 `shuffle_seeded` on `[0..codeword_len)` and passes the table through the FFI, so nothing
 on the GPU side depends on this file.
 """
@@ -41,12 +41,35 @@ class _RangeMixin:
         return result
 
 
+def seed_from_u64_words(seed_u64, n_words):
+    """rand_core::SeedableRng::seed_from_u64: the u64 seed expanded to n_words little-endian 32-bit words of seed
+    (PCG32 steps with increment 11634580027462260723, the state advanced BEFORE each output).  Pinned by rand_pcg's
+    construction vector (tests/golden/rand_vectors.json: pcg32_seed_from_u64)."""
+    state, words = seed_u64 & _M64, []
+    for _ in range(n_words):
+        state = (state * 6364136223846793005 + 11634580027462260723) & _M64
+        words.append(_pcg32_output(state))
+    return words
+
+
 class Pcg32(_RangeMixin):
     """rand_pcg::Lcg64Xsh32::new(state, stream): the generator rand's own value-stability tests use."""
 
     def __init__(self, state, stream):
         self.inc = ((stream << 1) | 1) & _M64
         self.state = ((state + self.inc) * 6364136223846793005 + self.inc) & _M64
+
+    @classmethod
+    def from_seed(cls, seed16):
+        """Lcg64Xsh32::from_seed: state = LE u64 of bytes 0..8, increment = LE u64 of bytes 8..16 | 1."""
+        g = cls.__new__(cls)
+        g.inc = (int.from_bytes(bytes(seed16[8:16]), "little") | 1) & _M64
+        g.state = ((int.from_bytes(bytes(seed16[:8]), "little") + g.inc) * 6364136223846793005 + g.inc) & _M64
+        return g
+
+    def next_u64(self):
+        lo = self.next_u32()
+        return lo | (self.next_u32() << 32)
 
     def next_u32(self):
         old = self.state
@@ -61,11 +84,7 @@ class ChaCha12Rng(_RangeMixin):
         if key_words is not None:  # SeedableRng::from_seed: eight little-endian key words
             key = [int(w) & _M32 for w in key_words]
         else:
-            state = seed_u64 & _M64
-            key = []
-            for _ in range(8):  # rand_core::SeedableRng::seed_from_u64 (PCG32 output function)
-                state = (state * 6364136223846793005 + 11634580027462260723) & _M64
-                key.append(_pcg32_output(state))
+            key = seed_from_u64_words(seed_u64, 8)  # rand_core::SeedableRng::seed_from_u64
         self.key, self.counter, self.buf, self.idx = key, 0, [], 16
 
     def _block(self):
