@@ -13,6 +13,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The compression in a fixed instruction order that alternates gfx950's double-rate VOP2 and single-rate VOP3
+// integer opcodes (tools/gen_blake3_sched.py, profiles/round3_valu_issue.md): 3.4 instead of 4.0 issue cycles per
+// instruction.  -DZIPK_B3_COMPILER_SCHED leaves the order to hipcc (A/B measurements).
+#include "blake3_sched.inc"
+
 namespace zipk {
 
 #define ZIPK_B3_IV0 0x6A09E667u
@@ -74,6 +79,25 @@ __device__ __forceinline__ void blake3_block(const uint32_t (&m)[16], uint32_t b
     h[7] = v7 ^ v15;
 }
 
+// One compression of a 64-byte message / of a 32-byte message (words 8..15 zero), in the scheduled order.
+__device__ __forceinline__ void blake3_block64(const uint32_t (&m)[16], uint32_t (&h)[8]) {
+#ifdef ZIPK_B3_COMPILER_SCHED
+    blake3_block(m, 64u, h);
+#else
+    blake3_sched_node(m, h);
+#endif
+}
+__device__ __forceinline__ void blake3_block32(const uint32_t (&m8)[8], uint32_t (&h)[8]) {
+#ifdef ZIPK_B3_COMPILER_SCHED
+    uint32_t m[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) m[i] = i < 8 ? m8[i] : 0u;
+    blake3_block(m, 32u, h);
+#else
+    blake3_sched_half(m8, h);
+#endif
+}
+
 // Parent node = BLAKE3(left.bytes || right.bytes), a plain 64-byte message
 // (NOT BLAKE3's parent-node mode): src/zip/pcs/utils.rs:107-112.
 __device__ __forceinline__ void blake3_node(const uint32_t (&l)[8], const uint32_t (&r)[8],
@@ -84,7 +108,7 @@ __device__ __forceinline__ void blake3_node(const uint32_t (&l)[8], const uint32
         m[i] = l[i];
         m[8 + i] = r[i];
     }
-    blake3_block(m, 64u, h);
+    blake3_block64(m, h);
 }
 
 // Leaf of a codeword entry whose 256-bit two's-complement value is the sign
@@ -94,18 +118,8 @@ __device__ __forceinline__ void blake3_node(const uint32_t (&l)[8], const uint32
 __device__ __forceinline__ void blake3_leaf_sext96(uint32_t d0, uint32_t d1, uint32_t d2,
                                                    uint32_t (&h)[8]) {
     const uint32_t s = (uint32_t)((int32_t)d2 >> 31);
-    uint32_t m[16];
-    m[0] = __builtin_bswap32(d1);
-    m[1] = __builtin_bswap32(d0);
-    m[2] = s;
-    m[3] = __builtin_bswap32(d2);
-    m[4] = s;
-    m[5] = s;
-    m[6] = s;
-    m[7] = s;
-#pragma unroll
-    for (int i = 8; i < 16; i++) m[i] = 0u;
-    blake3_block(m, 32u, h);
+    const uint32_t m[8] = {__builtin_bswap32(d1), __builtin_bswap32(d0), s, __builtin_bswap32(d2), s, s, s, s};
+    blake3_block32(m, h);
 }
 
 // Generic leaf of LIMBS 64-bit limbs (1..8), used by the standalone Merkle entry
@@ -123,7 +137,14 @@ __device__ __forceinline__ void blake3_leaf_limbs(const uint64_t (&limb)[LIMBS],
             m[2 * i + 1] = 0u;
         }
     }
-    blake3_block(m, 8u * LIMBS, h);
+    if constexpr (LIMBS == 4) {  // the Zip leaves (Int<4>); other widths only occur in the standalone zip_merkle_trees
+        const uint32_t m8[8] = {m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]};
+        blake3_block32(m8, h);
+    } else if constexpr (LIMBS == 8) {
+        blake3_block64(m, h);
+    } else {
+        blake3_block(m, 8u * LIMBS, h);
+    }
 }
 
 }  // namespace zipk

@@ -310,7 +310,7 @@ __device__ __forceinline__ void bfly_hash(Src &src, uint32_t (&h)[8]) {
             m[i] = up ? rcv : A[i];      // left child
             m[8 + i] = up ? B[i] : rcv;  // right child
         }
-        blake3_block(m, 64u, h);
+        blake3_block64(m, h);
         src.template store<LVL, E0>(h);
     }
 }
@@ -459,7 +459,7 @@ __device__ __forceinline__ uint32_t opaque_zero(uint32_t dep) {
 // plain one and is allowed 104 (4 x 104 of the 512 per SIMD still leave room for three gather waves, and the
 // gather's LDS image limits it to two workgroups per CU beside this kernel anyway).
 template <int E, bool HASH, int MODE = kStoreAll>
-__global__ void __launch_bounds__(1024, MODE != kStoreAll ? 4 : 5) raa_commit_kernel(CommitArgs a) {
+__global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
     constexpr bool MASKED = MODE != kStoreAll;
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int LOGE = (E == 1) ? 0 : (E == 2) ? 1 : (E == 4) ? 2 : 3;

@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(256) verify_columns_kernel(VerifyColsArgs a, F
                     m[i] = right ? sib[i] : cur[i];
                     m[8 + i] = right ? cur[i] : sib[i];
                 }
-                blake3_block(m, 64u, h);
+                blake3_block64(m, h);
 #pragma unroll
                 for (int i = 0; i < 8; i++) cur[i] = h[i];
                 index >>= 1;
