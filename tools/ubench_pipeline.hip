@@ -46,7 +46,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(p1d, p1.data(), cw * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(p2d, p2.data(), cw * 4, hipMemcpyHostToDevice));
     a.evals = evd; a.perm1 = p1d; a.perm2 = p2d; a.row_len = C; a.cw = cw; a.nact = cw / 8;
     a.num_rows = R; a.rounds_per_chunk = rpc; a.stamps = stamps_h; CK(hipMalloc(&a.roots, R * 32));
-    const size_t lds = 512 + (size_t)8 * (1024 + 4) * 12 + (size_t)C * 8;
+    const size_t lds = 512 + (size_t)8 * (1024 + 4) * 12 + (size_t)C * 8 + 4 * kFinisherFlagWords;
     auto kh = raa_commit_kernel<8, true>;
     CK(hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));

@@ -182,10 +182,29 @@ __device__ __forceinline__ void subtree_hash(Src &src, uint32_t (&h)[8]) {
 // rank is a per-wave base (pk_tab, row invariant, held in scalar registers) + the number of storing lanes below.
 constexpr int kStoreAll = 0, kStoreHinted = 1, kStorePacked = 3;
 
-template <int E, int MODE = kStoreAll>
+// LAZY: the lane's entries are not held in registers but read from LDS when their turn comes (entry of step e at
+// lz_lo / lz_hi [e * lz_stride]): the LDS planes are idle during the hash phase, and 3 E registers less are live at
+// the deepest point of the butterfly.
+template <int E, int MODE = kStoreAll, bool LAZY = false>
 struct StridedLeaves {
     static constexpr bool MASKED = MODE != kStoreAll;
-    uint32_t w0[E], w1[E], w2[E];  // 96-bit two's-complement values of the lane's E entries
+    uint32_t w0[E], w1[E], w2[E];  // 96-bit two's-complement values of the lane's E entries (!LAZY)
+    const uint64_t *lz_lo = nullptr;
+    const uint32_t *lz_hi = nullptr;
+    uint32_t lz_stride = 0;
+    template <int E0>
+    __device__ __forceinline__ void entry(uint32_t &a, uint32_t &b, uint32_t &c) const {
+        if (LAZY) {
+            const uint64_t lo = lz_lo[E0 * lz_stride];
+            a = (uint32_t)lo;
+            b = (uint32_t)(lo >> 32);
+            c = lz_hi[E0 * lz_stride];
+        } else {
+            a = w0[E0];
+            b = w1[E0];
+            c = w2[E0];
+        }
+    }
     uint64_t *out_row;
     uint32_t *tree;
     uint32_t cw, T, tid;
@@ -206,25 +225,33 @@ struct StridedLeaves {
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     }
     template <int E0>
-    __device__ __forceinline__ void store_row() {
+    __device__ __forceinline__ void store_row_of(uint32_t d0, uint32_t d1, uint32_t d2) {
         if (MASKED && !(smask & (1u << E0))) return;
         const uint32_t j = base + E0 * T + tid;
-        const uint32_t s = (uint32_t)((int32_t)w2[E0] >> 31);
+        const uint32_t s = (uint32_t)((int32_t)d2 >> 31);
         if (MODE == kStorePacked) {
             const uint32_t pos = pbase<E0>() + lanes_below(__builtin_amdgcn_ballot_w64(true));
-            *reinterpret_cast<uint4 *>(pk_row + (size_t)pos * 16) = make_uint4(w0[E0], w1[E0], w2[E0], s);
+            *reinterpret_cast<uint4 *>(pk_row + (size_t)pos * 16) = make_uint4(d0, d1, d2, s);
         } else if (compact) {
-            *reinterpret_cast<uint4 *>(out_row + (size_t)j * 2) = make_uint4(w0[E0], w1[E0], w2[E0], s);
+            *reinterpret_cast<uint4 *>(out_row + (size_t)j * 2) = make_uint4(d0, d1, d2, s);
         } else {
             uint4 *o = reinterpret_cast<uint4 *>(out_row + (size_t)j * 4);
-            o[0] = make_uint4(w0[E0], w1[E0], w2[E0], s);  // sign extension to Int<4>
+            o[0] = make_uint4(d0, d1, d2, s);  // sign extension to Int<4>
             o[1] = make_uint4(s, s, s, s);
         }
     }
     template <int E0>
+    __device__ __forceinline__ void store_row() {
+        uint32_t d0, d1, d2;
+        entry<E0>(d0, d1, d2);
+        store_row_of<E0>(d0, d1, d2);
+    }
+    template <int E0>
     __device__ __forceinline__ void leaf(uint32_t (&h)[8]) {
-        store_row<E0>();
-        blake3_leaf_sext96(w0[E0], w1[E0], w2[E0], h);
+        uint32_t d0, d1, d2;
+        entry<E0>(d0, d1, d2);
+        store_row_of<E0>(d0, d1, d2);
+        blake3_leaf_sext96(d0, d1, d2, h);
         if (!MASKED || (smask & (0x100u << E0))) {
             if (MODE == kStorePacked) {
                 const uint32_t pos = pbase<8 + E0>() + lanes_below(__builtin_amdgcn_ballot_w64(true));
@@ -315,12 +342,59 @@ __device__ __forceinline__ void bfly_hash(Src &src, uint32_t (&h)[8]) {
     }
 }
 
-// End of a chunk of rows of one workgroup of a persistent commit kernel: the tree levels
-// `first_level` .. depth of the rows it encoded in the chunk, level by level over all of them at once
-// (the first levels keep every lane busy, and the serial tail -- one node per row at the top -- is
-// paid once per chunk, not per row), the roots, then the publication of the chunk.  The children of
-// the first level were stored by this workgroup: a barrier makes them visible (one CU, one L1; the
-// lines were never read before they were written).
+// ---- end of a chunk of rows of one workgroup of a persistent commit kernel --------------------------------------
+// The butterflies leave level `first_level - 1` of every row in global memory; what remains are the levels
+// first_level .. depth of the chunk's rows, the roots, and the publication of the chunk.  Round-2 did all of it at
+// the chunk end, level by level with a barrier each: 47 us per chunk of four rows at 2^24 (a quarter useful work, the
+// rest a chain of ten dependent compressions by ever fewer lanes, the release fence and the re-start of the row
+// pipeline), 13 % of the kernel (profiles/round3_wg_spread.md).  Now:
+//   head   at the chunk end, all waves: ONE stage of two levels, every lane hashing the complete 4-leaf subtree over
+//          four consecutive nodes (three compressions, no exchange between lanes).  For cw = 8192 and chunks of four
+//          rows it keeps every lane busy: useful work at the full rate.
+//   rest   the remaining levels (6 .. depth), the roots, the release fence and the counter: AFTER the hash phase of
+//          the NEXT row, by the oldest wave of each SIMD (ChunkFinisher::after_hash); the chunk is published ~70 us
+//          later than before, which the consumer's slack absorbs.  The last chunk of the kernel has no next row: its
+//          rest runs at once, on wave 0.
+// Stages hand their nodes over through global memory (L2): a storing wave waits for its stores (vmcnt(0)) before the
+// barrier or the LDS counter that the loading wave passes afterwards.
+// Levels [lvl, lvl + nl) (nl = 1 or 2) of the rows of rounds first .. first + nrows_c - 1 of this workgroup from their
+// level lvl - 1 nodes; lane `lane` of `nlanes` takes every nlanes-th group of 2^nl nodes.
+__device__ __forceinline__ void upper_stage(const CommitArgs &a, uint32_t first, uint32_t nrows_c, uint32_t lvl, uint32_t nl,
+                                            uint32_t lane, uint32_t nlanes) {
+    const uint32_t cw = a.cw, depth = 31u - __builtin_clz(cw);
+    const uint32_t u_shift = depth - (lvl - 1u) - nl;  // log2(groups per row)
+    const uint32_t total = nrows_c << u_shift;
+    for (uint32_t idx = lane; idx < total; idx += nlanes) {
+        const uint32_t ri = idx >> u_shift, i = idx & ((1u << u_shift) - 1u);
+        const uint32_t r = blockIdx.x + (first + ri) * gridDim.x;
+        uint32_t *tree = a.layers + (size_t)r * (2u * cw) * 8;
+        const uint32_t *ch = tree + ((size_t)level_off(cw, lvl - 1u) + ((size_t)i << nl)) * 8;
+        uint32_t c0[8], c1[8], h0[8];
+        load_hash(ch, c0);
+        load_hash(ch + 8, c1);
+        if (nl == 1u) {
+            blake3_node(c0, c1, h0);
+            store_hash(tree + ((size_t)level_off(cw, lvl) + i) * 8, h0);
+            if (lvl == depth) store_hash(a.roots + (size_t)r * 8, h0);
+        } else {
+            uint32_t c2[8], c3[8], h1[8], h2[8];
+            blake3_node(c0, c1, h0);
+            uint32_t *o = tree + ((size_t)level_off(cw, lvl) + 2u * i) * 8;
+            store_hash(o, h0);
+            // (compiler barrier: the second pair is loaded only now -- all four children at once are 16 more live
+            // registers at the kernel's tightest point; the latency hides behind the other waves)
+            asm volatile("" ::: "memory");
+            load_hash(ch + 16, c2);
+            load_hash(ch + 24, c3);
+            blake3_node(c2, c3, h1);
+            store_hash(o + 8, h1);
+            blake3_node(h0, h1, h2);
+            store_hash(tree + ((size_t)level_off(cw, lvl + 1u) + i) * 8, h2);
+            if (lvl + 1u == depth) store_hash(a.roots + (size_t)r * 8, h2);
+        }
+    }
+}
+
 // The chunk schedule of a persistent commit kernel, tracked per workgroup in scalar registers.
 struct ChunkCursor {
     uint32_t first = 0, index = 0;  // first round and number of the chunk in progress
@@ -335,66 +409,130 @@ struct ChunkCursor {
     }
 };
 
-// Scratch for finish_chunk: two LDS regions that are dead between the hash phase of a chunk's last row and the scan
-// passes of the next row (the t2 planes).  The nodes of a level stay there for the next level, ping-pong.
-struct UpperScratch {
-    uint32_t *a, *b;       // 8 words per hash
-    uint32_t cap_a, cap_b;  // capacities in hashes
-};
+// LDS words a commit kernel reserves behind its own buffers for ChunkFinisher (one counter per deferred stage)
+constexpr uint32_t kFinisherFlagWords = 16;
 
 template <bool HASH>
-__device__ __forceinline__ void finish_chunk(const CommitArgs &a, uint32_t first_level, const ChunkCursor &cc,
-                                             uint32_t round, uint32_t tid, uint32_t T, const UpperScratch &us) {
-    const uint32_t cw = a.cw;
-    if (HASH) {
-        const uint32_t first = cc.first;
-        const uint32_t nrows_c = round - first + 1;
-        const uint32_t depth = 31u - __builtin_clz(cw);
-        __syncthreads();
-        // Levels first_level .. depth of the chunk's rows.  The first level reads its children (written by the
-        // butterflies of this workgroup) back from global memory; from then on a level's nodes are ALSO kept in LDS
-        // for the next one, so that the latency-bound top of the trees is a chain of LDS round trips with LDS-only
-        // barriers, not of L2 round trips with a store drain each (the global stores are fire-and-forget; the
-        // publication below waits for them once).  Falls back to global round trips where a level does not fit.
-        bool in_lds = false;           // the children of `lvl` are in LDS (at us.a or us.b)
-        uint32_t *src_lds = us.a;
-#ifdef ZIPK_EXP_NOFINISH  // timing experiment (tools/ubench_pipeline): what do the upper levels cost?
-        for (uint32_t lvl = first_level; lvl < first_level; lvl++) {
-#else
-        for (uint32_t lvl = first_level; lvl <= depth; lvl++) {
+struct ChunkFinisher {
+    // what the workgroup still owes of a finished chunk (wave-uniform): the levels from p_lvl up and the publication
+    bool pending = false;
+    uint32_t p_first = 0, p_nrows = 0, p_lvl = 0, p_index = 0;
+    uint32_t n_deferred = 0;  // chunks finished the deferred way so far (the flag counters count them)
+    uint32_t *flags = nullptr;  // LDS, kFinisherFlagWords zeroed words
+
+    __device__ __forceinline__ void init(uint32_t *lds_flags, uint32_t tid) {
+        flags = lds_flags;
+        if (tid < kFinisherFlagWords) lds_flags[tid] = 0;  // (every row has barriers long before the first use)
+    }
+
+    // top of a row iteration, every wave: its stores of a chunk that is still owed are in L2 before the barriers of
+    // this row (and before it issues this row's loads)
+    __device__ __forceinline__ void top_of_row() const {
+        if (HASH && pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    static __device__ __forceinline__ void publish(const CommitArgs &a, uint32_t index, uint32_t lane) {
+        if (!a.chunk_done) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+#ifndef ZIPK_EXP_NOFENCE  // timing experiment only (the gather may then read stale lines)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back has landed before the count moves
 #endif
-            const uint32_t wshift = depth - lvl;  // log2(width of this level)
-            const uint32_t total = nrows_c << wshift;
-            uint32_t *dst_lds = (in_lds && src_lds == us.a) ? us.b : us.a;
-            const uint32_t dst_cap = dst_lds == us.a ? us.cap_a : us.cap_b;
-            const bool keep = total <= dst_cap && lvl < depth;
-            for (uint32_t idx = tid; idx < total; idx += T) {
-                const uint32_t ri = idx >> wshift, i = idx & ((1u << wshift) - 1u);
-                const uint32_t r = blockIdx.x + (first + ri) * gridDim.x;
-                uint32_t *tree = a.layers + (size_t)r * (2u * cw) * 8;
-                uint32_t l[8], rr[8], h[8];
-                if (in_lds) {  // children of node idx of this level: nodes 2 idx, 2 idx + 1 of the level below, same row order
-                    load_hash(src_lds + (size_t)(2u * idx) * 8, l);
-                    load_hash(src_lds + (size_t)(2u * idx + 1u) * 8, rr);
-                } else {
-                    const uint32_t *ch = tree + ((size_t)level_off(cw, lvl - 1) + 2u * i) * 8;
-                    load_hash(ch, l);
-                    load_hash(ch + 8, rr);
-                }
-                blake3_node(l, rr, h);
-                store_hash(tree + ((size_t)level_off(cw, lvl) + i) * 8, h);
-                if (keep) store_hash(dst_lds + (size_t)idx * 8, h);
-                if (lvl == depth) store_hash(a.roots + (size_t)r * 8, h);
-            }
-            if (keep) {
-                lds_barrier();
-                in_lds = true;
-                src_lds = dst_lds;
-            } else {
-                __syncthreads();
-                in_lds = false;
-            }
+            __hip_atomic_fetch_add(&a.chunk_done[index], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+
+    // ONE wave, at once: the levels from `lvl` up, the roots, the publication (the last chunk of the kernel)
+    static __device__ __forceinline__ void tail(const CommitArgs &a, uint32_t first, uint32_t nrows_c, uint32_t lvl, uint32_t index,
+                                                uint32_t lane) {
+        const uint32_t cw = a.cw, depth = 31u - __builtin_clz(cw);
+        while (lvl <= depth) {
+            const uint32_t nl = depth - lvl >= 1u ? 2u : 1u;
+            upper_stage(a, first, nrows_c, lvl, nl, lane, 64u);
+            lvl += nl;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next stage loads what this one stored (same wave)
+        }
+        publish(a, index, lane);
+    }
+
+    // this wave's stores are in L2: count it in
+    static __device__ __forceinline__ void signal(uint32_t *flag, uint32_t lane) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // a wave parks until `target` waves have counted in.  The waves it waits for never wait for it (see after_hash), and
+    // they run: the spin is bounded only so that a bug ends in a trap, not in a hung GPU.
+    static __device__ __forceinline__ void wait_for(uint32_t *flag, uint32_t target) {
+        uint32_t spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 24)) __builtin_trap();
+        }
+    }
+
+    // After the hash phase of the row that FOLLOWS a chunk end.  The oldest wave of every SIMD (waves 0..3) finishes a
+    // hash phase ~45 us before the youngest (then it only waits at the next row's first barrier), and work added to a
+    // hash phase issues at the SIMD's mixed rate (3.4 cycles per instruction) where a lone wave at a chunk end runs at
+    // its dependent-issue rate (6).  So the levels above the head's stage are paid here, spread over the SIMDs:
+    //   stage 0 (two levels)   waves 0..W-1 together, a quarter of the groups each -> flag 0
+    //   stage j >= 1           ONE wave, (j - 1) mod W, once stage j-1 has counted in on flag j-1 -> flag j
+    //   publication            the wave of the last stage.
+    // A waiting wave has finished its own part of stage 0 before it waits, so nobody waits for a waiter.
+    __device__ __forceinline__ void after_hash(const CommitArgs &a, uint32_t wave, uint32_t lane, uint32_t T) {
+        if (!(HASH && pending)) return;
+        pending = false;
+        n_deferred++;
+        const uint32_t W = T >= 256u ? 4u : (T + 63u) / 64u;
+        if (wave >= W) return;
+        const uint32_t cw = a.cw, depth = 31u - __builtin_clz(cw);
+        uint32_t lvl = p_lvl, j = 0, owner = 0;
+        while (lvl <= depth) {
+            const uint32_t nl = depth - lvl >= 1u ? 2u : 1u;
+            if (j == 0) {
+                upper_stage(a, p_first, p_nrows, lvl, nl, lane + 64u * wave, 64u * W);
+                signal(flags, lane);
+            } else {
+                owner = (j - 1u) % W;
+                if (wave == owner) {
+                    wait_for(flags + (j - 1u), (j == 1u ? W : 1u) * n_deferred);
+                    upper_stage(a, p_first, p_nrows, lvl, nl, lane, 64u);
+                    signal(flags + j, lane);
+                }
+            }
+            lvl += nl;
+            j++;
+        }
+        if (wave == owner) {
+            if (j == 1u) wait_for(flags, W * n_deferred);  // stage 0 was the last one: everybody's part of it
+            publish(a, p_index, lane);
+        }
+    }
+
+    // the row of `round` ended chunk cc (every wave calls this)
+    __device__ __forceinline__ void chunk_end(const CommitArgs &a, uint32_t first_level, const ChunkCursor &cc, uint32_t round,
+                                              bool last, uint32_t tid, uint32_t T) {
+        const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+        if (!HASH) {  // encode_rows: nothing to hash, chunks are only ever published for a consumer of the rows
+            if (a.chunk_done) {
+                __syncthreads();
+                if (wave == 0) publish(a, cc.index, lane);
+            }
+            return;
+        }
+        const uint32_t cw = a.cw, depth = 31u - __builtin_clz(cw);
+        const uint32_t first = cc.first, nrows_c = round - first + 1;
+        __syncthreads();  // every wave's nodes of level first_level - 1 are in L2
+        uint32_t lvl = first_level;
+#ifndef ZIPK_EXP_NOFINISH  // timing experiment (tools/wg_spread.py): what do the upper levels cost?
+        if (lvl <= depth) {  // the head: one stage with every lane at work
+            const uint32_t nl = depth - lvl >= 1u ? 2u : 1u;
+            upper_stage(a, first, nrows_c, lvl, nl, tid, T);
+            lvl += nl;
+        }
+#else
+        lvl = depth + 1;
+#endif
         if (depth == 0 && tid == 0) {  // a one-leaf tree: the root is the leaf hash
             for (uint32_t ri = 0; ri < nrows_c; ri++) {
                 const uint32_t r = blockIdx.x + (first + ri) * gridDim.x;
@@ -403,18 +541,18 @@ __device__ __forceinline__ void finish_chunk(const CommitArgs &a, uint32_t first
                 store_hash(a.roots + (size_t)r * 8, h);
             }
         }
-    }
-    if (a.chunk_done) {
-        __syncthreads();  // every wave's stores are issued and waited for (vmcnt(0) + barrier)
-        if (tid == 0) {
-#ifndef ZIPK_EXP_NOFENCE  // timing experiment only (the gather may then read stale lines)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back has landed before the count moves
-#endif
-            __hip_atomic_fetch_add(&a.chunk_done[cc.index], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (last) {  // no next row to hide the rest behind
+            __syncthreads();
+            if (wave == 0) tail(a, first, nrows_c, lvl, cc.index, lane);
+        } else {
+            pending = true;
+            p_first = first;
+            p_nrows = nrows_c;
+            p_lvl = lvl;
+            p_index = cc.index;
         }
     }
-}
+};
 
 __device__ __forceinline__ void stamp_clock(const CommitArgs &a, int slot) {
     if (a.clock && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -476,21 +614,27 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
     uint64_t *t2lo = reinterpret_cast<uint64_t *>(smem + 512);         // E planes of PS slots
     uint32_t *t2hi = reinterpret_cast<uint32_t *>(t2lo + E * PS);
     int64_t *rowbuf = reinterpret_cast<int64_t *>(t2hi + E * PS);
-    // the t2 planes are dead while a chunk is finished: ping-pong space for the upper tree levels
-    const UpperScratch us{reinterpret_cast<uint32_t *>(t2lo), t2hi, (uint32_t)(E * PS * 8 / 32), (uint32_t)(E * PS * 4 / 32)};
-    // Row-invariant state kept in registers so that no global load sits on the per-row critical
-    // path: the thread's permutation indices (packed: pi1 source index | pi2 LDS slot << 16) ...
+    // The thread's permutation indices (packed: pi1 source index | pi2 LDS slot << 16).
+    // They are RE-READ EVERY ROW (64 bytes per thread from tables that live in L2, ~1.4 us per row): held across the
+    // hash phase their 8 registers -- with the entries, now read from LDS when their turn comes -- were what kept the
+    // kernel at 104-108 VGPRs; without them it needs 86, and 160 instead of 96 registers per SIMD lane are left to the
+    // kernels that run beside it (-DZIPK_PIDX_IN_REGISTERS: the round-2 form, for A/B runs).
     uint32_t pidx[E];
+    auto load_pidx = [&](uint32_t t) {
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        uint32_t v1 = 0, v2 = 0;
-        if (active) {
-            v1 = a.perm1[tid0 * E + e] & (row_len - 1);  // repeat: t0[j] = row[j mod row_len]
-            const uint32_t p2 = a.perm2[tid0 * E + e];
-            v2 = (p2 & (E - 1)) * PS + (p2 >> LOGE);
+        for (int e = 0; e < E; e++) {
+            uint32_t v1 = 0, v2 = 0;
+            if (active) {
+                v1 = a.perm1[t * E + e] & (row_len - 1);  // repeat: t0[j] = row[j mod row_len]
+                const uint32_t p2 = a.perm2[t * E + e];
+                v2 = (p2 & (E - 1)) * PS + (p2 >> LOGE);
+            }
+            pidx[e] = v1 | (v2 << 16);
         }
-        pidx[e] = v1 | (v2 << 16);
-    }
+    };
+#ifdef ZIPK_PIDX_IN_REGISTERS
+    load_pidx(tid0);
+#endif
     // ... the lane's store mask under an opening hint ...
     const uint32_t smask = (MASKED && active) ? store_mask<E>(a.need, cw, 0u, a.nact, tid0) : 0xFFFFFFFFu;
     // ... and (packed openings) the wave's base ranks, wave-uniform
@@ -518,10 +662,14 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
 #endif
     uint32_t round = 0;
     ChunkCursor cc;
+    ChunkFinisher<HASH> fin;
+    fin.init(reinterpret_cast<uint32_t *>(rowbuf + row_len), tid0);
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     for (uint32_t row = blockIdx.x; row < a.num_rows; row += gridDim.x, round++) {
 #ifdef ZIPK_DEBUG_STAMPS
         ph_t = wall_clock64();
 #endif
+        fin.top_of_row();
         const uint32_t z = opaque_zero(row);
         const uint32_t tid = tid0 + z;
         const int64_t *in = a.evals + (size_t)row * row_len;
@@ -540,6 +688,9 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
         }
 
         i128 v[E];
+#ifndef ZIPK_PIDX_IN_REGISTERS
+        load_pidx(tid);  // (`tid` is opaque: the loads stay inside the loop)
+#endif
         // ---- pass 1: repeat + permute(pi1) + accumulate ------------------------
         if (active) {
 #pragma unroll
@@ -601,7 +752,7 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
         lds_barrier();
         ZIPK_PH(ph_a);
         if (active) {
-            StridedLeaves<E, MODE> src;
+            StridedLeaves<E, MODE, true> src;
             src.out_row = out_row;
             src.compact = a.compact_rows;
             src.tree = HASH ? a.layers + (size_t)row * (2u * cw) * 8 : nullptr;
@@ -617,14 +768,13 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) src.ptab[k] = ptab[k];
             }
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                const uint32_t j = e * a.nact + tid;
-                const uint32_t slot = (j & (E - 1)) * PS + (j >> LOGE);
-                const uint64_t lo = t2lo[slot];
-                src.w0[e] = (uint32_t)lo;
-                src.w1[e] = (uint32_t)(lo >> 32);
-                src.w2[e] = t2hi[slot];
+            {
+                // entry j = e * nact + tid sits at slot (j % E) * PS + j / E; nact is a multiple of E (or E = 1), so the
+                // slot of step e is the slot of step 0 + e * nact / E: read when its turn comes (StridedLeaves LAZY)
+                const uint32_t slot0 = (tid & (E - 1)) * PS + (tid >> LOGE);
+                src.lz_lo = t2lo + slot0;
+                src.lz_hi = t2hi + slot0;
+                src.lz_stride = a.nact >> LOGE;
             }
             if (HASH) {
                 uint32_t top[8];
@@ -634,10 +784,11 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
             }
         }
         ZIPK_PH(ph_b);
-        // ---- finish a chunk: upper Merkle levels of this workgroup's rows, then publish ------
+        // ---- wave 0: the tail of the previous chunk; then, if this row ends a chunk, its head ------
+        fin.after_hash(a, wave0, tid0 & 63u, T);
         const bool last = row + gridDim.x >= a.num_rows;
         if (cc.ends_with(a, round, last)) {
-            finish_chunk<HASH>(a, LOGE + 1, cc, round, tid, T, us);
+            fin.chunk_end(a, LOGE + 1, cc, round, last, tid, T);
             cc.advance(round);
         }
         ZIPK_PH(ph_c);
@@ -679,8 +830,8 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
 // T threads x 16 entries: T = 1024 for cw = 16384 (one workgroup per CU), T = 512 for cw = 8192, where TWO
 // workgroups fit a CU (2 x 74.8 KB of LDS): while one of them is in its scan passes or in the latency-bound top
 // of its tree, the other one hashes.
-constexpr size_t c16_lds_bytes(uint32_t T) {  // wave totals | t2lo [16][T+2] | t2dh [16][T+2] | ghi [T]
-    return 512 + (size_t)16 * (T + 2) * 8 + (size_t)16 * (T + 2) + (size_t)T * 4;
+constexpr size_t c16_lds_bytes(uint32_t T) {  // wave totals | t2lo [16][T+2] | t2dh [16][T+2] | ghi [T] | finisher flags
+    return 512 + (size_t)16 * (T + 2) * 8 + (size_t)16 * (T + 2) + (size_t)T * 4 + 64;
 }
 
 // One stage of the 8x8 transpose over the lanes of an 8-lane group: registers r and r | 2^B are
@@ -724,9 +875,6 @@ __global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
     // second half of the outputs (phase B) waits in the dead t2 planes
     uint64_t *park_lo = reinterpret_cast<uint64_t *>(smem + 512);         // [8][PS]
     uint32_t *park_hi = reinterpret_cast<uint32_t *>(park_lo + (size_t)8 * PS);  // [8][PS]
-    // ... and, while a chunk is finished, its two halves are ping-pong space for the upper tree levels
-    const UpperScratch us{reinterpret_cast<uint32_t *>(t2lo), reinterpret_cast<uint32_t *>(t2lo + (size_t)8 * PS),
-                          (uint32_t)(8 * PS * 8 / 32), (uint32_t)(8 * PS * 8 / 32)};
 
     // row-invariant store masks of the two output phases under an opening hint
     const uint32_t smask0 = MASKED ? store_mask<8>(a.need, cw, 0u, 16u, (tid0 & ~7u) * 16u + (tid0 & 7u)) : 0xFFFFFFFFu;
@@ -745,7 +893,11 @@ __global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
 
     uint32_t round = 0;
     ChunkCursor cc;
+    ChunkFinisher<HASH> fin;
+    fin.init(reinterpret_cast<uint32_t *>(ghi + T), tid0);
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     for (uint32_t row = blockIdx.x; row < a.num_rows; row += gridDim.x, round++) {
+        fin.top_of_row();
         const uint32_t z = opaque_zero(row);
         const uint32_t tid = tid0 + z;
         const int64_t *in = a.evals + (size_t)row * row_len;
@@ -865,9 +1017,10 @@ __global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
                 store_rows_only<8, 0>(src);
             }
         }
+        fin.after_hash(a, wave0, tid0 & 63u, T);
         const bool last = row + gridDim.x >= a.num_rows;
         if (cc.ends_with(a, round, last)) {
-            finish_chunk<HASH>(a, 4u, cc, round, tid, T, us);
+            fin.chunk_end(a, 4u, cc, round, last, tid, T);
             cc.advance(round);
         }
     }

@@ -781,7 +781,7 @@ int32_t ensure_dynamic_lds(zip_ctx *ctx, const void *kern, size_t bytes) {
 template <int E, bool HASH, int MODE = kStoreAll>
 int32_t launch_commit(zip_ctx *ctx, const CommitArgs &a, uint32_t threads, uint32_t grid, hipStream_t st) {
     // wave totals + E planes of (threads + 32/E) slots of 12 bytes + the witness row (+ the opening tables)
-    size_t lds = 512 + (size_t)E * (threads + 32 / E) * 12 + (size_t)a.row_len * 8;
+    size_t lds = 512 + (size_t)E * (threads + 32 / E) * 12 + (size_t)a.row_len * 8 + 4 * kFinisherFlagWords;
     auto kern = raa_commit_kernel<E, HASH, MODE>;
     if (int32_t rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds)) return rc;
     LaunchTimer t(ctx, HASH ? "raa_commit_kernel" : "raa_encode_kernel", st);
@@ -822,7 +822,7 @@ CommitGeom commit_geom(uint32_t cw, uint32_t row_len) {
     else if (cw == 256) { g.e = 4; g.threads = 64; }
     else if (cw == 128) { g.e = 2; g.threads = 64; }
     else { g.e = 1; g.threads = 64; }  // cw <= 64: one entry per lane
-    g.lds = 512 + (size_t)g.e * (g.threads + 32 / g.e) * 12 + (size_t)row_len * 8;
+    g.lds = 512 + (size_t)g.e * (g.threads + 32 / g.e) * 12 + (size_t)row_len * 8 + 4 * kFinisherFlagWords;
     return g;
 }
 // resident workgroups per CU of the commit kernel (threads and LDS)
