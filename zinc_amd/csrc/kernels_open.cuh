@@ -10,6 +10,7 @@
 //                                      src/zip/pcs_transcript.rs:115-135,198-211
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace zipk {
@@ -581,6 +582,119 @@ __global__ void __launch_bounds__(256) open_columns_stream_kernel(OpenColsArgs a
         o.y = is_hdr ? v.x : val_hi ? sw : v.y;
         *reinterpret_cast<oc_u128_a8 *>(dst) = o;
     }
+}
+
+// The openings with as little VALU work as they can be made with (round 3).  Beside the VALU-bound commit kernel a
+// gather pays for every vector-ALU instruction it issues with the hashing waves' time -- its loads, stores and scalar
+// instructions issue on other ports -- and open_columns_kernel / open_columns_stream_kernel spend ~100 VALU instructions
+// per wave and 32 rows on 64-bit pointer walks, loop counters held per lane and data selects (49.8 M per step at 2^24:
+// 6.5 % of the commit kernel's own, and that is what the commit kernel ran slower beside them).  Here:
+//   * one workgroup takes MANY rows of one opening (rows_per_block, 128 by default): the per-lane set-up -- role,
+//     node offset, rank look-up -- is paid once per 128 rows instead of once per 32;
+//   * the walk over the rows is two instructions per pass (one v_lshl_add_u64 each for the source and the destination
+//     pointer); the pass count is wave-uniform (scalar loop), the last partial pass is predicated once;
+//   * no data selects: the record header is its own lane role that only stores (8 bytes, a constant), the upper
+//     half of a compact row entry's Int<4> (the sign word four times) is four dword stores of the loaded sign word;
+//   * no LDS, no barrier: every lane moves its 16 bytes straight from the tree / the packed block to the stream
+//     (8-byte-aligned records: global_store_dwordx4 at dword alignment).
+// Lane roles of the SLOTS lanes reserved per row (h = lane % SLOTS):
+//   h < 2 depth      half (h & 1) of the level-(h >> 1) sibling            h == 2 depth + 1   value, low 16 bytes
+//   h == 2 depth     be64(depth), the record's first 8 bytes               h == 2 depth + 2   value, high 16 bytes
+struct __attribute__((packed, aligned(4))) oc_u32_a4 { uint32_t x; };
+
+template <int SLOTS>
+__global__ void __launch_bounds__(256) open_columns_lean_kernel(OpenColsArgs a) {
+    constexpr uint32_t K = 4;               // Int<4> column values (checked by zip_ctx_create)
+    constexpr uint32_t RPP = 256 / SLOTS;   // rows per pass of the block
+    if (a.prio) __builtin_amdgcn_s_setprio(2);
+    const uint32_t ci = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    const uint32_t col = a.cols[ci];
+    const uint32_t d = a.depth, cw2 = 2u * a.cw;
+    const uint32_t rec_bytes = 8 + 32 * d;
+    const size_t col_bytes = (size_t)a.num_rows * (8 * K + rec_bytes);
+    uint8_t *base = a.out + (size_t)ci * col_bytes;
+    const uint32_t r0 = a.row_lo + blockIdx.y * a.rows_per_block;
+    const uint32_t r1 = min(r0 + a.rows_per_block, a.row_hi);
+    const uint32_t nrows = r1 - r0;
+    const uint32_t h = threadIdx.x & (SLOTS - 1), rsub = threadIdx.x / SLOTS;
+    if (h > 2 * d + 2) return;
+    const bool is_hdr = h == 2 * d, is_val = h > 2 * d;
+    const uint32_t half = is_val ? h - 2 * d - 1 : (h & 1u);
+    const uint32_t lvl = (is_hdr || is_val) ? 0u : h >> 1;
+    const uint32_t row = r0 + rsub;
+    const bool val_hi_compact = is_val && half && a.compact_rows;
+    // source: a tree node (or its packed copy), or the column's row entry
+    const uint8_t *src;
+    size_t src_step;
+    if (is_val) {
+        if (a.pk) {
+            src = a.pk + (size_t)row * a.pk_stride + (size_t)a.pk_rank[ci * 4] * 16;
+            src_step = (size_t)RPP * a.pk_stride;
+        } else if (a.compact_rows) {
+            src = reinterpret_cast<const uint8_t *>(a.rows + ((size_t)row * a.cw + col) * 2);
+            src_step = (size_t)RPP * a.cw * 16;
+        } else {
+            src = reinterpret_cast<const uint8_t *>(a.rows + ((size_t)row * a.cw + col) * K + half * 2);
+            src_step = (size_t)RPP * a.cw * 8 * K;
+        }
+    } else if (a.pk && lvl < 3) {
+        const uint32_t off = lvl == 0 ? a.pk_off0 : lvl == 1 ? a.pk_off1 : a.pk_off2;
+        src = a.pk + (size_t)row * a.pk_stride + off + (size_t)a.pk_rank[ci * 4 + 1 + lvl] * 32 + half * 16u;
+        src_step = (size_t)RPP * a.pk_stride;
+    } else {
+        const uint32_t node = cw2 - (cw2 >> lvl) + ((col >> lvl) ^ 1u);
+        src = reinterpret_cast<const uint8_t *>(a.layers + ((size_t)row * cw2 + node) * 4) + half * 16u;
+        src_step = (size_t)RPP * cw2 * 32;
+    }
+    uint8_t *dst = is_val ? base + (size_t)row * 8 * K + half * 16
+                          : base + (size_t)a.num_rows * 8 * K + (size_t)row * rec_bytes + (is_hdr ? 0u : 8u + h * 16u);
+    const size_t dst_step = is_val ? (size_t)RPP * 8 * K : (size_t)RPP * rec_bytes;
+    const uint64_t hdr = __builtin_bswap64((uint64_t)d);
+    const uint32_t full = nrows / RPP, rest = nrows % RPP;  // wave-uniform: the loops below are scalar loops
+    // N passes at once: all loads first (N x 16 bytes in flight per lane), then the stores by role.  The N source and
+    // destination addresses are formed ONCE, ahead of the role branches.
+    auto passes = [&](auto n_tag) {
+        constexpr int N = decltype(n_tag)::value;
+        const uint8_t *sk[N];
+        uint8_t *dk[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            sk[k] = src + k * src_step;
+            dk[k] = dst + k * dst_step;
+        }
+        asm volatile("" ::: "memory");  // (keeps the address arithmetic out of the divergent regions below)
+        uint4 v[N];
+        if (!is_hdr) {
+#pragma unroll
+            for (int k = 0; k < N; k++) v[k] = *reinterpret_cast<const uint4 *>(sk[k]);
+        }
+        if (is_hdr) {
+#pragma unroll
+            for (int k = 0; k < N; k++) *reinterpret_cast<uint64_t *>(dk[k]) = hdr;
+        } else if (val_hi_compact) {
+            // (w0, w1, w2, sign) -> the Int<4>'s upper two limbs: the sign word four times, as four dword stores of the
+            // ONE register that holds it (a dwordx4 store would want three copies first: VALU work on every wave)
+#pragma unroll
+            for (int k = 0; k < N; k++)
+                asm volatile("global_store_dword %0, %1, off\n\tglobal_store_dword %0, %1, off offset:4\n\t"
+                             "global_store_dword %0, %1, off offset:8\n\tglobal_store_dword %0, %1, off offset:12"
+                             :: "v"(dk[k]), "v"(v[k].w) : "memory");
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                oc_u128_a8 o;
+                o.x = ((uint64_t)v[k].y << 32) | v[k].x;
+                o.y = ((uint64_t)v[k].w << 32) | v[k].z;
+                *reinterpret_cast<oc_u128_a8 *>(dk[k]) = o;
+            }
+        }
+        src += N * src_step;
+        dst += N * dst_step;
+    };
+    uint32_t p = 0;
+    for (; p + 4 <= full; p += 4) passes(std::integral_constant<int, 4>{});
+    for (; p < full; p++) passes(std::integral_constant<int, 1>{});
+    if (rsub < rest) passes(std::integral_constant<int, 1>{});
 }
 
 }  // namespace zipk

@@ -95,7 +95,7 @@ struct zip_ctx {
     // chunk, and `stream` everything else (row combinations, column openings, copies).  Per-chunk
     // events let the memory-bound column gather of chunk k overlap the VALU-bound hashing of
     // chunk k+1.
-    hipStream_t stream = nullptr, s_commit = nullptr, s_upper = nullptr, s_aux = nullptr;
+    hipStream_t stream = nullptr, s_commit = nullptr, s_upper = nullptr, s_aux = nullptr, s_gather2 = nullptr;
     uint32_t n_chunks = 1;
     uint32_t num_cus = 256;
     uint32_t *timeout_flag_h = nullptr, *timeout_flag_d = nullptr;  // pinned: a pipeline wait gave up
@@ -1179,8 +1179,9 @@ void gather_order(const uint32_t *cols, uint32_t n_cols, uint32_t *order) {
 // `first_opening`: cols_dv points at opening number first_opening of the list the handle was hinted with (a packed
 // handle's rank table is indexed by the opening; zip_open_stream emits the list in groups).
 int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_cols, uint8_t *out_d,
-                         uint32_t row_lo, uint32_t row_hi, uint32_t first_opening = 0) {
+                         uint32_t row_lo, uint32_t row_hi, uint32_t first_opening = 0, hipStream_t st = nullptr) {
     zip_ctx *ctx = c->ctx;
+    if (!st) st = ctx->stream;
     if (n_cols == 0 || row_hi <= row_lo) return ZIP_OK;
     OpenColsArgs a{};
     a.rows = c->rows;
@@ -1226,25 +1227,42 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
     // the kernel without an LDS image.  ZIP_HIP_GATHER_STREAM=1 / 0 forces it on / off.
     static const int knob_stream = getenv("ZIP_HIP_GATHER_STREAM") ? atoi(getenv("ZIP_HIP_GATHER_STREAM")) : -1;
     const bool stream = knob_stream >= 0 ? knob_stream == 1 : rpb < 32;
+    // ZIP_HIP_GATHER_LEAN=1: the kernel with the fewest VALU instructions (many rows per workgroup, no LDS, no data
+    // selects).  Opt-in: beside the commit kernel it is the slower choice -- 1.92-2.01 against 1.80-1.85 ms per step,
+    // the commit kernel 1.64-1.72 instead of 1.57 ms: what a gather costs the hashing waves is its VECTOR-MEMORY
+    // instructions (it has four times as many as the LDS-image kernel below), not its VALU ones (EXPERIMENTS.md).
+    static const int knob_lean = getenv("ZIP_HIP_GATHER_LEAN") ? atoi(getenv("ZIP_HIP_GATHER_LEAN")) : 0;
+    if (knob_lean && ctx->depth >= 1 && 2 * ctx->depth + 3 <= 64) {
+        const uint32_t want = (knob_rpb >= 2 && knob_rpb <= 4096) ? knob_rpb : 128u;
+        a.rows_per_block = (row_hi - row_lo) < want ? (row_hi - row_lo) : want;
+        const dim3 grid(n_cols, (row_hi - row_lo + a.rows_per_block - 1) / a.rows_per_block), block(256);
+        LaunchTimer t(ctx, "open_columns_kernel", st);
+        if (2 * ctx->depth + 3 <= 32)
+            hipLaunchKernelGGL(open_columns_lean_kernel<32>, grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL(open_columns_lean_kernel<64>, grid, block, 0, st, a);
+        HIP_TRY(ctx, hipGetLastError());
+        return ZIP_OK;
+    }
     if (stream && ctx->depth >= 1 && 2 * ctx->depth + 3 <= 64) {
         const uint32_t want = (knob_rpb >= 2 && knob_rpb <= 4096) ? knob_rpb : 32u;
         a.rows_per_block = (row_hi - row_lo) < want ? (row_hi - row_lo) : want;
         const dim3 grid(n_cols, (row_hi - row_lo + a.rows_per_block - 1) / a.rows_per_block), block(256);
-        LaunchTimer t(ctx, "open_columns_kernel");
+        LaunchTimer t(ctx, "open_columns_kernel", st);
         if (2 * ctx->depth + 3 <= 32)
-            hipLaunchKernelGGL(open_columns_stream_kernel<32>, grid, block, 0, ctx->stream, a);
+            hipLaunchKernelGGL(open_columns_stream_kernel<32>, grid, block, 0, st, a);
         else
-            hipLaunchKernelGGL(open_columns_stream_kernel<64>, grid, block, 0, ctx->stream, a);
+            hipLaunchKernelGGL(open_columns_stream_kernel<64>, grid, block, 0, st, a);
         HIP_TRY(ctx, hipGetLastError());
         return ZIP_OK;
     }
     const size_t lds = (size_t)a.rows_per_block * (8 + 32 * (size_t)ctx->depth);
     const dim3 grid(n_cols, (row_hi - row_lo + a.rows_per_block - 1) / a.rows_per_block), block(256);
-    LaunchTimer t(ctx, "open_columns_kernel");
+    LaunchTimer t(ctx, "open_columns_kernel", st);
     if (2 * ctx->depth + 1 <= 32)
-        hipLaunchKernelGGL(open_columns_kernel<32>, grid, block, lds, ctx->stream, a);
+        hipLaunchKernelGGL(open_columns_kernel<32>, grid, block, lds, st, a);
     else
-        hipLaunchKernelGGL(open_columns_kernel<64>, grid, block, lds, ctx->stream, a);
+        hipLaunchKernelGGL(open_columns_kernel<64>, grid, block, lds, st, a);
     HIP_TRY(ctx, hipGetLastError());
     return ZIP_OK;
 }
@@ -1259,21 +1277,41 @@ int32_t run_open_columns_pipelined(zip_commitment *c, const uint32_t *cols_dv, u
         return run_open_columns(c, cols_dv, n_cols, out_d, 0, ctx->rows_local);
     }
     if (c->zeroed) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, c->zeroed, 0));
+    // The gathers of consecutive chunks do not depend on each other, only each on ITS chunk.  ZIP_HIP_GATHER_STREAMS=2
+    // alternates them between two streams, so that the next chunk's wait + gather is already in place when a gather
+    // ends (two dependent launches in one stream cost ~28 us per chunk boundary).  Measured (round 3): WORSE, 1.96-2.00
+    // against 1.88 ms per step on one box -- gathers that overlap each other take longer in sum (1.9 against 1.26 ms of
+    // kernel time per step) and slow the commit kernel more.  One stream is the default.
+    static const bool two_streams = getenv("ZIP_HIP_GATHER_STREAMS") && atoi(getenv("ZIP_HIP_GATHER_STREAMS")) == 2;
+    hipStream_t gs[2] = {ctx->stream, (two_streams && ctx->s_gather2 && c->bounds.size() > 2) ? ctx->s_gather2 : ctx->stream};
+    if (gs[1] != gs[0]) {
+        hipEvent_t fork = take_dep_event(ctx);
+        c->aux.push_back(fork);
+        HIP_TRY(ctx, hipEventRecord(fork, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(gs[1], fork, 0));
+    }
     // test hook: an unreachable target and a 1 ms limit exercise the recovery path of a timed-out wait
     // (a value > 1 is the limit in ticks of the 100 MHz clock: short enough and the gathers run BEFORE their rows exist)
     const char *force_env = getenv("ZIP_HIP_FORCE_WAIT_TIMEOUT");
     const bool force_timeout = force_env != nullptr;
     const unsigned long long force_ticks = (force_env && atoll(force_env) > 1) ? (unsigned long long)atoll(force_env) : 100000ull;
     for (size_t k = 0; k + 1 < c->bounds.size(); k++) {
+        hipStream_t st = gs[k & 1];
         {
-            LaunchTimer t(ctx, "wait_counter_kernel");
-            hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, ctx->stream, c->chunk_done + k,
+            LaunchTimer t(ctx, "wait_counter_kernel", st);
+            hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, st, c->chunk_done + k,
                                force_timeout ? 0xFFFFFFFFu : c->expected[k], 0u, ctx->timeout_flag_d,
                                force_timeout ? force_ticks : 25000000ull /* 0.25 s at 100 MHz */);
             HIP_TRY(ctx, hipGetLastError());
         }
-        int32_t rc = run_open_columns(c, cols_dv, n_cols, out_d, c->bounds[k], c->bounds[k + 1]);
+        int32_t rc = run_open_columns(c, cols_dv, n_cols, out_d, c->bounds[k], c->bounds[k + 1], 0, st);
         if (rc) return rc;
+    }
+    if (gs[1] != gs[0]) {
+        hipEvent_t join = take_dep_event(ctx);
+        c->aux.push_back(join);
+        HIP_TRY(ctx, hipEventRecord(join, gs[1]));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, join, 0));
     }
     return ZIP_OK;
 }
@@ -1768,7 +1806,8 @@ int32_t zip_ctx_create(const zip_params *p, zip_ctx **out) {
         if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
             hipStreamCreateWithPriority(&ctx->s_commit, hipStreamNonBlocking, prio_hi) != hipSuccess ||
             hipStreamCreateWithPriority(&ctx->s_upper, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-            hipStreamCreateWithPriority(&ctx->s_aux, hipStreamNonBlocking, prio_lo) != hipSuccess) {
+            hipStreamCreateWithPriority(&ctx->s_aux, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+            hipStreamCreateWithPriority(&ctx->s_gather2, hipStreamNonBlocking, prio_lo) != hipSuccess) {
             rc = ZIP_ERR_HIP;
             break;
         }
@@ -1827,6 +1866,7 @@ void zip_ctx_destroy(zip_ctx *ctx) {
     if (ctx->s_commit) (void)stream_wait(ctx->s_commit);
     if (ctx->s_upper) (void)stream_wait(ctx->s_upper);
     if (ctx->s_aux) (void)stream_wait(ctx->s_aux);
+    if (ctx->s_gather2) (void)stream_wait(ctx->s_gather2);
     if (ctx->stream) (void)stream_wait(ctx->stream);
     ctx->hint_plan.reset();  // (its device block goes back to the pool that is torn down next)
     *ctx->alive = false;
@@ -1846,6 +1886,7 @@ void zip_ctx_destroy(zip_ctx *ctx) {
     if (ctx->s_commit) (void)hipStreamDestroy(ctx->s_commit);
     if (ctx->s_upper) (void)hipStreamDestroy(ctx->s_upper);
     if (ctx->s_aux) (void)hipStreamDestroy(ctx->s_aux);
+    if (ctx->s_gather2) (void)hipStreamDestroy(ctx->s_gather2);
     if (ctx->stage_big) (void)hipHostFree(ctx->stage_big);
     for (auto *h : ctx->hint_free) (void)hipHostFree(h);
     for (auto *h : ctx->job_stage)
@@ -1879,6 +1920,7 @@ int32_t zip_ctx_synchronize(zip_ctx *ctx) {
     if (ctx->s_commit) HIP_TRY(ctx, stream_wait(ctx->s_commit));
     if (ctx->s_upper) HIP_TRY(ctx, stream_wait(ctx->s_upper));
     if (ctx->s_aux) HIP_TRY(ctx, stream_wait(ctx->s_aux));
+    if (ctx->s_gather2) HIP_TRY(ctx, stream_wait(ctx->s_gather2));
     HIP_TRY(ctx, stream_wait(ctx->stream));
     return check_timeout(ctx);
 }
