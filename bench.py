@@ -163,9 +163,12 @@ def run_mctx(args, torch, dist, rank, world, cabi, perm1, perm2, zf, coeffs, col
     HBM (each shard's openings on its own device, u' and the evaluation row on the lead device).  Under torchrun only
     rank 0 works; the other ranks wait at the barriers.  BENCH_MCTX_DEVICES=0,0,0,0 repeats a device (one-GPU box)."""
     n = 1 << nv
-    ndev = args.devices or max(world, 1)
+    ndev = args.devices or (args.gpus if world == 1 else world)
     devs = ([int(x) for x in os.environ["BENCH_MCTX_DEVICES"].split(",")] if "BENCH_MCTX_DEVICES" in os.environ
             else list(range(ndev)))
+    if rank == 0 and max(devs) >= cabi.device_count():
+        raise SystemExit(f"--gpus {ndev}: this box has {cabi.device_count()} device(s); to rehearse {ndev} row shards on "
+                         f"one GPU set BENCH_MCTX_DEVICES=" + ",".join(["0"] * ndev))
     m = None
     if rank == 0:
         m = cabi.ZipMultiContext(nv, perm1, perm2, devs)
@@ -183,7 +186,8 @@ def run_mctx(args, torch, dist, rank, world, cabi, perm1, perm2, zf, coeffs, col
         step()
     barrier()
     if m is not None:
-        m.shard_profile(0, on=True)
+        for sh in range(len(devs)):
+            m.shard_profile(sh, on=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -199,7 +203,9 @@ def run_mctx(args, torch, dist, rank, world, cabi, perm1, perm2, zf, coeffs, col
         commit_bytes = per * row_len * 8 + per * cw * 32 * 3
         out = {
             "metric": "Zip commit+open MCoeffs/s at 2^%d witness" % nv, "value": round(n / step_s / 1e6, 2), "unit": "MCoeffs/s",
-            "n_gpus": len(devs), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4),
+            "n_gpus": len(devs), "distinct_devices": len(set(devs)),
+            "roots_gather": m.roots_path(),  # "rccl": in-process ncclAllGather over xGMI; "copies": repeated ordinals (rehearsal)
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i64",
             "data": "synthetic (SplitMix64 full-range i64 witness; coefficient / column / point streams per SURVEY.md 8d)",
             "config": {"workload": "Zip commit+open_z 2^%d coeffs, ONE polynomial row-sharded over %d device context(s) by one process (zip_mctx)" % (nv, len(devs)),
@@ -212,7 +218,11 @@ def run_mctx(args, torch, dist, rank, world, cabi, perm1, perm2, zf, coeffs, col
             "whole_path": {"algorithmic_bytes": int(sum(ab.values())),
                            "hbm_frac_per_gpu": round(sum(ab.values()) / step_s / 1e9 / HBM_PEAK_GBS / len(devs), 4)},
             "kernels_ms_per_step_shard0": {k: round(v[1] / args.steps, 4) for k, v in sorted(ktimes.items())},
+            # the dominant kernel of every shard (ms per launch): on distinct GPUs they run side by side
+            "commit_kernel_ms_per_shard": [round(v[1] / max(v[0], 1), 4) for v in
+                                           (m.shard_profile(sh).get("raa_commit_kernel", (1, 0.0)) for sh in range(1, len(devs)))],
         }
+        out["commit_kernel_ms_per_shard"].insert(0, round(avg_ms, 4))
         print(json.dumps(out), flush=True)
         m.close()
     if world > 1:
@@ -287,6 +297,11 @@ def main():
     coeffs, cols, q0 = host_inputs(nv, row_len, num_rows, cw, fl, args.seed)
     n_cols = cols.size
 
+    if world == 1 and args.gpus > 1 and args.shard == "polys":
+        # `python3 bench.py --gpus N` without a launcher: ONE process drives the N GPUs through the C ABI's multi-device
+        # context (strong scaling of one polynomial, the roots gathered with in-process RCCL) -- what a Rust ZincProver,
+        # one process making one call, would use.  Under torchrun (WORLD_SIZE = N) the default stays `polys`.
+        args.shard = "mctx"
     if args.shard == "mctx":
         return run_mctx(args, torch, dist, rank, world, cabi, perm1, perm2, zf, coeffs, cols, q0, nv, row_len, num_rows, cw, depth, fl)
     rows_mode = args.shard == "rows" and world > 1

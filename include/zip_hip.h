@@ -16,9 +16,10 @@
  *  - plain C types only; every call returns int32 (ZIP_OK == 0, negative = error)
  *  - no exceptions / unwinding cross the boundary; zip_strerror() names a code and
  *    zip_ctx_last_error() returns the detailed message of the last failing call
- *  - one zip_ctx per GPU and per geometry; one process per GPU (multi-GPU runs
- *    give every rank its own ctx with a row shard, and exchange roots / partial
- *    rows with RCCL above this ABI)
+ *  - one zip_ctx per GPU and per geometry.  Several GPUs: either ONE process drives them all through the
+ *    multi-device context below -- row shards behind one call, the roots gathered with in-process RCCL --, or one process
+ *    per GPU gives every rank its own ctx with a row shard and exchanges roots / partial rows with RCCL above
+ *    this ABI (zinc_amd/dist.py)
  *  - all work is enqueued on the ctx's HIP stream; calls that write HOST memory
  *    return after the data has landed, calls that only touch DEVICE memory return
  *    asynchronously (use zip_ctx_synchronize)
@@ -400,6 +401,13 @@ int32_t zip_mctx_shard_openings(zip_mctx *m, uint32_t shard, uint8_t **ptr, size
                                 uint32_t *row_count);
 /* after zip_mctx_commit_open: u' (u_bytes) followed by the evaluation row (row_bytes) on the lead device */
 int32_t zip_mctx_ends(zip_mctx *m, uint8_t **ptr, size_t *u_bytes, size_t *row_bytes);
+/* after zip_mctx_commit_open: the commitment -- the roots of ALL rows, [num_rows][32] -- as shard's device holds it.
+ * The concatenation of the per-row roots (src/zip/pcs/commit.rs:78-81) is the one exchange of a row-sharded commit:
+ * over distinct devices it is one grouped ncclAllGather (ncclBroadcast per owner for uneven blocks) on in-process
+ * RCCL communicators (ncclCommInitAll; librccl is bound with dlopen when such a zip_mctx is created), over repeated
+ * ordinals -- or when RCCL is missing or refuses -- device copies.  zip_mctx_roots_path: "rccl" | "copies" | "none". */
+int32_t zip_mctx_roots(zip_mctx *m, uint32_t shard, uint8_t **ptr);
+const char *zip_mctx_roots_path(const zip_mctx *m);
 
 /* ---- standalone Merkle tree --------------------------------------------------------
  * MerkleTree::new (pcs/utils.rs:74-85) over num_trees * 2^depth leaves of leaf_limbs

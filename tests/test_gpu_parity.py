@@ -559,6 +559,40 @@ def test_two_jobs_in_flight_recover_from_timed_out_waits(cabi, monkeypatch):
     assert np.array_equal(outs[1].cpu().numpy(), np.asarray(want[0]))
 
 
+def _device_bytes(ptr, n):
+    """n bytes at device address ptr (device 0) -> numpy, through a zero-copy torch view"""
+    import torch
+
+    holder = type("_H", (), {})()
+    holder.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(holder, device="cuda:0").cpu().numpy()
+
+
+@pytest.mark.parametrize("shards", [1, 2, 4])
+def test_multi_device_context_on_the_2pow26_geometry(cabi, shards):
+    """zip_mctx over cw = 16384 (raa_commit16_kernel, packed openings, the image-free gather): a 16-row slice of the
+    BASELINE configs[3] geometry, sharded by rows; proof, roots and the gathered commitment equal the oracle's."""
+    nv, geo = 17, (8192, 16, 16384)
+    z = orc.Zip(nv, geometry=geo)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    evals = _witness(nv, seed=43)
+    point = orc.point_to_field(f, np.arange(5, nv + 5, dtype=np.int64))
+    rows_o, layers_o, roots_o = z.commit(evals)
+    proof_o, cols, coeffs = z.open(f, evals, rows_o, layers_o, point, orc.new_transcript())
+    lr = z.num_rows.bit_length() - 1
+    q0 = orc.build_eq_x_r(f, point[nv - lr:])
+    m = cabi.ZipMultiContext(nv, z.perm1, z.perm2, [0] * shards, geometry_override=geo)
+    for evals_arg in (evals, None):  # host witness, then the slices it left on the devices
+        proof, roots = m.commit_open(evals_arg, coeffs, cols, q0, zf)
+        assert np.array_equal(roots, roots_o)
+        bad = np.flatnonzero(proof != proof_o)
+        assert bad.size == 0, f"{bad.size} proof bytes differ, first at {bad[:8]}"
+        for sh in range(shards):
+            assert np.array_equal(_device_bytes(m.roots_ptr(sh), z.num_rows * 32).reshape(z.num_rows, 32), roots_o), sh
+    m.close()
+
+
 @pytest.mark.parametrize("num_vars", [12, 16, 18])
 @pytest.mark.parametrize("shards", [1, 2, 3, 4, 8])
 def test_multi_device_context_proof_equals_unsharded(cabi, num_vars, shards):
@@ -581,6 +615,11 @@ def test_multi_device_context_proof_equals_unsharded(cabi, num_vars, shards):
     assert np.array_equal(roots, roots_o)
     bad = np.flatnonzero(proof != proof_o)
     assert bad.size == 0, f"{bad.size} proof bytes differ, first at {bad[:8]}"
+    # the one exchange of the commit: every shard's device holds the roots of ALL rows (commit.rs:78-81).  One shard
+    # on device 0 is a one-rank in-process RCCL communicator (the real ncclAllGather path); repeated ordinals copy.
+    assert m.roots_path() == ("rccl" if shards == 1 else "copies"), m.roots_path()
+    for sh in range(shards):
+        assert np.array_equal(_device_bytes(m.roots_ptr(sh), z.num_rows * 32).reshape(z.num_rows, 32), roots_o), sh
     # witness resident on the devices, second call through the same context (buffers reused)
     m.set_witness(evals)
     proof2, roots2 = m.commit_open(None, coeffs, cols, q0, zf)

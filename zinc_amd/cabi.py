@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "zip_open_columns", "zip_open_eval", "zip_proof_len", "zip_open", "zip_sum_partials", "zip_merkle_trees",
     "zip_ctx_set_profiling", "zip_ctx_profile_read", "zip_ctx_commit_clock",
     "zip_mctx_create", "zip_mctx_destroy", "zip_mctx_last_error", "zip_mctx_shards", "zip_mctx_shard_ctx", "zip_mctx_set_witness",
-    "zip_mctx_commit_open", "zip_mctx_shard_openings", "zip_mctx_ends", "zip_verify", "zip_mle_eval", "zip_commitment_mle_eval", "zip_field_map_int256",
+    "zip_mctx_commit_open", "zip_mctx_shard_openings", "zip_mctx_ends", "zip_mctx_roots", "zip_mctx_roots_path", "zip_verify", "zip_mle_eval", "zip_commitment_mle_eval", "zip_field_map_int256",
     "zip_open_stream", "zip_sumcheck_init", "zip_sumcheck_round", "zip_sumcheck_round_begin", "zip_sumcheck_round_end", "zip_sumcheck_last_error", "zip_sumcheck_free",
     "zip_ccs_create", "zip_ccs_free", "zip_ccs_last_error", "zip_ccs_set_z", "zip_ccs_eq_table",
     "zip_ccs_second_table", "zip_ccs_table", "zip_ccs_download", "zip_ccs_eval_matrices",
@@ -242,6 +242,10 @@ def lib():
     L.zip_mctx_shard_openings.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32),
                                           C.POINTER(C.c_uint32)]
     L.zip_mctx_ends.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.zip_mctx_roots.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
+    L.zip_mctx_roots.restype = C.c_int32
+    L.zip_mctx_roots_path.argtypes = [vp]
+    L.zip_mctx_roots_path.restype = C.c_char_p
     for fn in ("zip_mctx_create", "zip_mctx_set_witness", "zip_mctx_commit_open", "zip_mctx_shard_openings", "zip_mctx_ends"):
         getattr(L, fn).restype = C.c_int32
     for fn in ("zip_ctx_create", "zip_ctx_synchronize", "zip_commit", "zip_commit_hinted", "zip_commitment_device_ptrs",
@@ -546,6 +550,16 @@ class ZipMultiContext:
 
     def shards(self):
         return lib().zip_mctx_shards(self._h)
+
+    def roots_ptr(self, shard):
+        """Device address (on shard's device) of the gathered commitment: the roots of ALL rows, [num_rows][32]."""
+        p = C.c_void_p()
+        self._check(lib().zip_mctx_roots(self._h, shard, C.byref(p)), "zip_mctx_roots")
+        return p.value
+
+    def roots_path(self):
+        """How the roots reached every device in the last commit_open: "rccl", "copies" or "none"."""
+        return (lib().zip_mctx_roots_path(self._h) or b"").decode()
 
     def shard_profile(self, s, on=None):
         """Profiling hooks of shard s's context: on=True/False switches, None reads {kernel: (launches, ms)}."""

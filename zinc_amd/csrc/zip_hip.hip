@@ -4,6 +4,7 @@
 // validation mirroring the reference's error behaviour, kernel dispatch and the
 // HIP-event measurement hooks used by bench.py.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -898,7 +899,8 @@ static void plan_packed(HintPlan &P) {
     P.L.stride = at;
 }
 // zip_commit_open stores the low part of the openings packed where the commit kernel has the variant (whole waves of
-// 8 or 16 entries per thread, depth >= 3) and the packed rows fit the buffer of the 16-byte row entries they replace
+// 8 or 16 entries per thread, depth >= 3); the packed rows take the place of the 16-byte row entries (commit_impl sizes
+// the buffer for whichever is larger: at cw <= 4096 a row's packed block exceeds its compact entries)
 static std::shared_ptr<HintPlan> get_hint_plan(zip_ctx *ctx, const uint32_t *cols, uint32_t n_cols, bool want_packed) {
     const uint32_t cw = ctx->p.codeword_len;
     const CommitGeom g = commit_geom(cw, ctx->p.row_len);
@@ -929,7 +931,7 @@ static std::shared_ptr<HintPlan> get_hint_plan(zip_ctx *ctx, const uint32_t *col
         ctx->depth >= 3) {
         plan_packed(*P);
         P->own_ranks.resize((size_t)n_cols * 4);
-        P->packed = P->L.stride > 0 && (size_t)P->L.stride <= (size_t)cw * 16 && P->wave_tab.size() * 4 <= kPackedRanksAt - kHintTables &&
+        P->packed = P->L.stride > 0 && P->wave_tab.size() * 4 <= kPackedRanksAt - kHintTables &&
                     kPackedRanksAt + P->own_ranks.size() * 2 <= kHintBytes && P->ranks(cols, n_cols, P->own_ranks.data());
     }
     // the tables go to the device here, once, not with every commit
@@ -1963,7 +1965,16 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
         static const bool no_compact = getenv("ZIP_HIP_NO_COMPACT_ROWS") != nullptr;
         c->compact_rows = with_merkle && !no_compact;
         c->rows_bytes = (size_t)R * cw * (c->compact_rows ? 16 : 32);
-        if ((rc = pool_alloc(ctx, c->rows_bytes, (void **)&c->rows))) break;
+        {
+            // packed openings take the place of the 16-byte row entries; where a row's packed block is larger than they
+            // are (cw <= 4096 with 1000 openings) the buffer is sized for it
+            size_t alloc = c->rows_bytes;
+            if (with_merkle && hint_cols && commit_supports_hint(cw)) {
+                const auto plan = get_hint_plan(ctx, hint_cols, n_hint, c->compact_rows && n_hint && packed_enabled());
+                if (plan->packed) alloc = std::max(alloc, (size_t)R * plan->L.stride);
+            }
+            if ((rc = pool_alloc(ctx, alloc, (void **)&c->rows))) break;
+        }
         if (with_merkle) {
             c->layers_bytes = (size_t)R * 2 * cw * 32;
             c->roots_bytes = (size_t)R * 32;
@@ -1982,12 +1993,16 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
         const CommitGeom geom = commit_geom(cw, C);
         uint32_t G = ctx->num_cus * commit_wgs_per_cu(geom);
         if (G > R) G = R;
+        // (A commit whose rows all fit ONE round of resident workgroups -- 2^20: 1024 rows, four 256-thread workgroups
+        // per CU -- has nothing to pipeline.  Half the workgroups and two rounds was tried: the kernel takes 240 instead
+        // of 131 us, a round of 2 workgroups per CU lasts as long as one of 4 -- latency-bound at that size.)
         const uint32_t rounds = (R + G - 1) / G;
         // rows_per_chunk also batches the in-kernel upper tree levels, so keep it even without
         // chunk signalling (commit_no_merkle has neither)
         // default: chunks of four rounds (measured best at 2^22 / 2^23 / 2^24: 1 / 2 / 4 chunks) -- fewer
         // rounds per chunk starve the batched upper levels, more leave the gather too little to overlap
-        uint32_t nch = !with_merkle ? 1 : ctx->n_chunks ? ctx->n_chunks : std::min(8u, std::max(1u, rounds / 4));
+        // (few rounds -- 2^20 .. 2^22, or an eighth of 2^24 in a zip_mctx shard -- : two chunks, so that there is an overlap)
+        uint32_t nch = !with_merkle ? 1 : ctx->n_chunks ? ctx->n_chunks : rounds >= 8 ? std::min(8u, rounds / 4) : rounds >= 2 ? 2u : 1u;
         if (nch > rounds) nch = rounds;
         const uint32_t rpc = (rounds + nch - 1) / nch;
         nch = (rounds + rpc - 1) / rpc;
@@ -2550,7 +2565,7 @@ static int32_t open_enqueue(zip_commitment *c, const int64_t *evals_d, const int
         return rc;
     if (place == 2) {
         if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o))) return rc;
-    } else if (place == 4 && c->done && c->chunk_done) {
+    } else if (place == 4 && c->done) {
         // the fold of the partial sums on its own stream, as soon as the commit kernel has ended (only then do its
         // 126 VGPRs fit on a CU): beside the gather of the last chunk instead of behind it
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_aux, staged, 0));
@@ -2781,9 +2796,58 @@ struct zip_mctx {
     uint8_t *ends = nullptr;             // lead device: u' (row_len * 64) | evaluation row big-endian (row_len * 8 fl)
     size_t ends_cap = 0;
     uint32_t last_cols = 0, last_fl = 0;
+    // the one exchange of the commit (commit.rs:78-81): every shard's roots on EVERY device, [num_rows][32].
+    // Distinct devices: an in-process RCCL communicator per shard (ncclCommInitAll) and one grouped all-gather over
+    // xGMI; repeated ordinals (several shards on one GPU: the one-GPU rehearsal) or no librccl: device copies.
+    std::vector<uint8_t *> roots_all;
+    std::vector<void *> nccl_comm;  // ncclComm_t per shard, or empty
+    std::string roots_path = "none";
     std::string last_error;
     std::mutex mu;
 };
+
+// librccl is bound at run time (dlopen), only by a zip_mctx over several distinct devices: libzip_hip.so itself has no
+// RCCL dependency, and a process that already carries an RCCL (PyTorch's) gets that copy.
+namespace rccl {
+typedef int (*comm_init_all_t)(void **comms, int ndev, const int *devlist);
+typedef int (*comm_destroy_t)(void *comm);
+typedef int (*group_t)(void);
+typedef int (*all_gather_t)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t st);
+typedef int (*broadcast_t)(const void *send, void *recv, size_t count, int dtype, int root, void *comm, hipStream_t st);
+typedef const char *(*err_str_t)(int);
+struct Api {
+    void *lib = nullptr;
+    comm_init_all_t comm_init_all = nullptr;
+    comm_destroy_t comm_destroy = nullptr;
+    group_t group_start = nullptr, group_end = nullptr;
+    all_gather_t all_gather = nullptr;
+    broadcast_t broadcast = nullptr;
+    err_str_t err_str = nullptr;
+    bool ok = false;
+};
+constexpr int kUint8 = 1;  // ncclUint8 (= ncclChar + 1; rccl.h ncclDataType_t)
+static Api &api() {
+    static Api a;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (getenv("ZIP_HIP_NO_RCCL")) return;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) return;
+        a.comm_init_all = (comm_init_all_t)dlsym(a.lib, "ncclCommInitAll");
+        a.comm_destroy = (comm_destroy_t)dlsym(a.lib, "ncclCommDestroy");
+        a.group_start = (group_t)dlsym(a.lib, "ncclGroupStart");
+        a.group_end = (group_t)dlsym(a.lib, "ncclGroupEnd");
+        a.all_gather = (all_gather_t)dlsym(a.lib, "ncclAllGather");
+        a.broadcast = (broadcast_t)dlsym(a.lib, "ncclBroadcast");
+        a.err_str = (err_str_t)dlsym(a.lib, "ncclGetErrorString");
+        a.ok = a.comm_init_all && a.comm_destroy && a.group_start && a.group_end && a.all_gather && a.broadcast;
+    });
+    return a;
+}
+}  // namespace rccl
 
 static int32_t mfail(zip_mctx *m, int32_t code, const char *what, zip_ctx *from = nullptr) {
     m->last_error = std::string(what) + (from ? std::string(": ") + from->last_error : std::string());
@@ -2806,12 +2870,15 @@ void zip_mctx_destroy(zip_mctx *m) {
         if (s < m->upart.size()) pool_release(ctx, m->upart[s]);
         if (s < m->fpart.size()) pool_release(ctx, m->fpart[s]);
         if (s < m->combined.size() && m->combined[s]) (void)hipEventDestroy(m->combined[s]);
+        if (s < m->roots_all.size()) pool_release(ctx, m->roots_all[s]);
         if (s == 0) {
             pool_release(ctx, m->uparts_all);
             pool_release(ctx, m->fparts_all);
             pool_release(ctx, m->ends);
         }
     }
+    for (void *c : m->nccl_comm)
+        if (c && rccl::api().ok) (void)rccl::api().comm_destroy(c);
     for (zip_ctx *ctx : m->shard) zip_ctx_destroy(ctx);
     delete m;
 }
@@ -2856,6 +2923,21 @@ int32_t zip_mctx_create(const zip_params *p, int32_t n_devices, const int32_t *d
             }
         }
     }
+    if (!rc) {
+        m->roots_all.assign(G, nullptr);
+        bool distinct = true;
+        for (uint32_t s = 0; s < G; s++)
+            for (uint32_t t = 0; t < s; t++) distinct &= devices[s] != devices[t];
+        if (distinct && rccl::api().ok) {
+            m->nccl_comm.assign(G, nullptr);
+            std::vector<int> devs(devices, devices + G);
+            const int e = rccl::api().comm_init_all(m->nccl_comm.data(), (int)G, devs.data());
+            if (e != 0) {  // (not fatal: the roots then travel as peer copies; zip_mctx_roots_path says which)
+                m->last_error = std::string("ncclCommInitAll failed: ") + (rccl::api().err_str ? rccl::api().err_str(e) : "?");
+                m->nccl_comm.clear();
+            }
+        }
+    }
     if (rc) {
         zip_mctx_destroy(m);
         return rc;
@@ -2863,6 +2945,17 @@ int32_t zip_mctx_create(const zip_params *p, int32_t n_devices, const int32_t *d
     *out = m;
     return ZIP_OK;
 }
+
+// The commitment of the last zip_mctx_commit_open as every device holds it: the roots of ALL rows, [num_rows][32], on
+// shard s's device (valid until the next call on m).
+int32_t zip_mctx_roots(zip_mctx *m, uint32_t s, uint8_t **ptr) {
+    if (!m || !ptr || s >= m->shard.size()) return ZIP_ERR_NULL;
+    *ptr = s < m->roots_all.size() ? m->roots_all[s] : nullptr;
+    return *ptr ? ZIP_OK : ZIP_ERR_INVALID_PARAM;
+}
+// "rccl" (grouped ncclAllGather / ncclBroadcast over the in-process communicators), "copies" (device copies: repeated
+// ordinals, or librccl missing / refused) or "none" (no zip_mctx_commit_open yet)
+const char *zip_mctx_roots_path(const zip_mctx *m) { return m ? m->roots_path.c_str() : ""; }
 
 // Places the witness on the devices: shard s gets its rows.  evals: HOST, the whole polynomial.
 int32_t zip_mctx_set_witness(zip_mctx *m, const int64_t *evals, size_t n_evals) {
@@ -3011,6 +3104,58 @@ int32_t zip_mctx_commit_open(zip_mctx *m, const int64_t *evals, const int64_t *c
                               cscr.back().get(), 2)))
             return finish(mfail(m, rc, "combine", ctx));
         if (hipEventRecord(m->combined[s], ctx->stream) != hipSuccess) return finish(mfail(m, ZIP_ERR_HIP, "event record failed"));
+    }
+    // ---- 1b. the roots of every shard onto every device (the commitment is device-resident everywhere), on the
+    //          shards' commit streams: behind their commit kernels, beside their openings
+    {
+        for (uint32_t s = 0; s < G; s++) {
+            zip_ctx *ctx = m->shard[s];
+            if (hipSetDevice(ctx->device) != hipSuccess) return finish(mfail(m, ZIP_ERR_HIP, "hipSetDevice failed"));
+            if (!m->roots_all[s] && (rc = pool_alloc(ctx, (size_t)R * 32, (void **)&m->roots_all[s]))) return finish(mfail(m, rc, "roots", ctx));
+        }
+        bool even = true;
+        for (uint32_t s = 0; s < G; s++) even &= m->shard[s]->rows_local == m->shard[0]->rows_local;
+        bool done = false;
+        if (!m->nccl_comm.empty()) {
+            rccl::Api &N = rccl::api();
+            int e = N.group_start();
+            for (uint32_t s = 0; s < G && e == 0; s++) {
+                zip_ctx *ctx = m->shard[s];
+                (void)hipSetDevice(ctx->device);
+                if (even) {
+                    e = N.all_gather(com[s]->roots, m->roots_all[s], (size_t)ctx->rows_local * 32, rccl::kUint8, m->nccl_comm[s], ctx->s_commit);
+                } else {  // uneven blocks of rows (3 shards): one broadcast per owner
+                    for (uint32_t root = 0; root < G && e == 0; root++) {
+                        zip_ctx *rc_ = m->shard[root];
+                        e = N.broadcast(com[root]->roots, m->roots_all[s] + (size_t)rc_->p.row_begin * 32, (size_t)rc_->rows_local * 32,
+                                        rccl::kUint8, (int)root, m->nccl_comm[s], ctx->s_commit);
+                    }
+                }
+            }
+            const int e2 = N.group_end();
+            if (e == 0 && e2 == 0) {
+                done = true;
+                m->roots_path = "rccl";
+            } else {
+                m->last_error = std::string("RCCL roots gather failed (falling back to copies): ") + (N.err_str ? N.err_str(e ? e : e2) : "?");
+            }
+        }
+        if (!done) {
+            // device copies: every destination pulls every owner's slice once that owner's commit has finished
+            for (uint32_t s = 0; s < G; s++) {
+                zip_ctx *ctx = m->shard[s];
+                if (hipSetDevice(ctx->device) != hipSuccess) return finish(mfail(m, ZIP_ERR_HIP, "hipSetDevice failed"));
+                for (uint32_t o = 0; o < G; o++) {
+                    zip_ctx *oc = m->shard[o];
+                    hipError_t e = com[o]->done ? hipStreamWaitEvent(ctx->s_commit, com[o]->done, 0) : hipSuccess;
+                    if (e == hipSuccess)
+                        e = hipMemcpyPeerAsync(m->roots_all[s] + (size_t)oc->p.row_begin * 32, ctx->device, com[o]->roots, oc->device,
+                                               (size_t)oc->rows_local * 32, ctx->s_commit);
+                    if (e != hipSuccess) return finish(mfail(m, ZIP_ERR_HIP, hipGetErrorString(e)));
+                }
+            }
+            m->roots_path = "copies";
+        }
     }
     // ---- 2. lead shard: pull the partial rows together and add them up (exactly)
     if (hipSetDevice(lead->device) != hipSuccess) return finish(mfail(m, ZIP_ERR_HIP, "hipSetDevice failed"));
