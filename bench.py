@@ -399,6 +399,30 @@ def main():
                      "api": "zip_commit_open_begin / zip_job_wait",
                      "note": "the same steps queued as jobs, two in flight; `value` above is one proof at a time"}
 
+    two_call = None
+    if world == 1 and not rows_mode and not (args.two_calls or args.no_hint):
+        # The two calls an UNCHANGED ZincProver makes (src/zinc/prover.rs:315-320): plain zip_commit -- no columns in its
+        # signature -- then zip_open.  The first opening names the columns; from then on the ctx hints its plain commits
+        # with that list on its own (zip_hip.h: zip_ctx_set_speculation), so this leg should match `value`.
+        def step2():
+            com, _ = ctx.commit(evals_d, want_roots=False)
+            com.open(evals_d, coeffs, cols, q0, zf, out=proof)
+            com.free()
+
+        proof_one_call = proof.clone()
+        for _ in range(max(args.warmup, 2)):
+            step2()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step2()
+        barrier()
+        dt2c = time.perf_counter() - t1
+        two_call = {"api": "zip_commit + zip_open (no column argument to the commit; speculative hint from the ctx's last opening)",
+                    "steps": args.steps, "ms_per_step": round(dt2c / args.steps * 1e3, 4),
+                    "value": round(n * args.steps / dt2c / 1e6, 2), "unit": "MCoeffs/s",
+                    "proof_identical_to_one_call": bool(torch.equal(proof, proof_one_call))}
+
     in_flight = None
     if args.in_flight > 1 and world == 1 and not rows_mode:
         # Independent jobs (separate provers' polynomials) overlapped: the end of one job's opening -- the last chunk's
@@ -521,6 +545,8 @@ def main():
             "kernels_ms_per_step": dict({k: round(v[1] / steps_all, 4) for k, v in sorted(ktimes_all.items())},
                                         **{dom: round(avg_ms * launches / args.steps, 4)}),
         }
+        if two_call:
+            out["two_call_unchanged_api"] = two_call
         if pipelined:
             out["pipelined"] = pipelined
         if in_flight:

@@ -130,6 +130,16 @@ void zip_commitment_free(zip_commitment *c);
  * re-runs the commit in full from the witness, transparently; for that a DEVICE
  * `evals` must stay valid and unchanged until the handle is freed.  Geometries below codeword_len 512 ignore
  * the hint. */
+/* zip_commit and the opening hint: a ctx whose zip_open / zip_open_stream has named a column list hints its NEXT plain
+ * zip_commit calls (with_merkle != 0) with that list on its own -- in the prover's flow (commit, then open on a fresh
+ * PcsTranscript: src/zinc/prover.rs:315-320) the columns never change, so the two unchanged calls run at the hinted
+ * commit's speed and produce the same bytes.  The handle's semantics stay zip_commit's: whatever it is asked for that
+ * the hint did not keep completes it first (a transparent re-run: from the witness zip_open was handed again, from the
+ * library's copy of a HOST witness, or from the caller's DEVICE witness -- whose digest, taken beside the commit
+ * kernel, must then still match: ZIP_ERR_INVALID_PARAM otherwise).  on = 0 switches the speculation off for the ctx
+ * (ZIP_HIP_SPECULATE=0: for the process). */
+int32_t zip_ctx_set_speculation(zip_ctx *ctx, int32_t on);
+
 int32_t zip_commit_hinted(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
                           const uint32_t *cols, uint32_t n_cols, uint8_t *roots_out, zip_commitment **out);
 

@@ -559,6 +559,79 @@ def test_two_jobs_in_flight_recover_from_timed_out_waits(cabi, monkeypatch):
     assert np.array_equal(outs[1].cpu().numpy(), np.asarray(want[0]))
 
 
+@pytest.mark.parametrize("num_vars", [16, 20])
+def test_plain_commit_speculates_with_the_last_columns(cabi, num_vars):
+    """The two UNCHANGED calls of ZincProver (commit, then open on a fresh transcript: prover.rs:315-320): after a first
+    opening the ctx hints its plain zip_commit with that column list.  Byte-identical proofs for commit -> open (same
+    columns: the fast path), commit -> open (OTHER columns: transparent re-run from the witness zip_open is handed),
+    commit -> download (re-run from the device witness, digest intact); a DEVICE witness overwritten in between is
+    refused, not silently re-read."""
+    torch = pytest.importorskip("torch")
+    z = orc.Zip(num_vars)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    evals = _witness(num_vars, seed=77)
+    point = orc.point_to_field(f, np.arange(num_vars, dtype=np.int64) + 9)
+    rows_o, layers_o, roots_o = z.commit(evals)
+    proof_o, cols, coeffs = z.open(f, evals, rows_o, layers_o, point, orc.new_transcript())
+    lr = z.num_rows.bit_length() - 1
+    q0 = orc.build_eq_x_r(f, point[num_vars - lr:])
+    ctx = _ctx(cabi, z)
+    d = torch.from_numpy(evals).cuda()
+    ctx.set_profiling(True)
+    # 1. nothing seen yet: a full commit; its opening names the columns
+    com, roots = ctx.commit(d)
+    assert np.array_equal(roots, roots_o)
+    assert np.array_equal(com.open(d, coeffs, cols, q0, zf), proof_o)
+    com.free()
+    ctx.profile_read()
+    # 2. the fast path: ONE commit launch, the same bytes
+    com, roots = ctx.commit(d)
+    assert np.array_equal(roots, roots_o)
+    assert np.array_equal(com.open(d, coeffs, cols, q0, zf), proof_o)
+    assert ctx.profile_read()["raa_commit_kernel"][0] == 1
+    # ... and the same handle opened with OTHER columns completes itself first (second launch) -- right bytes again
+    cols2 = ((cols[::-1].astype(np.int64) + 3) % z.codeword_len).astype(np.uint32)
+    plain = _ctx(cabi, z)
+    plain.set_speculation(False)  # (a fully materialised commitment opened with cols2: checked against the oracle elsewhere)
+    c_full, _ = plain.commit(d)
+    want2 = c_full.open(d, coeffs, cols2, q0, zf)
+    c_full.free()
+    assert not np.array_equal(want2, proof_o)
+    assert np.array_equal(com.open(d, coeffs, cols2, q0, zf), want2)
+    assert ctx.profile_read()["raa_commit_kernel"][0] == 1
+    com.free()
+    # 3. commit -> download: everything the reference's MultilinearZipData holds
+    com, _ = ctx.commit(d)  # (hinted with cols2 now: the last opening's list)
+    rows, layers, roots3 = com.download()
+    assert np.array_equal(rows, rows_o) and np.array_equal(roots3, roots_o)
+    assert np.array_equal(layers, layers_o[:, : 2 * z.codeword_len - 2])
+    com.free()
+    # 4. a device witness overwritten between the commit and the completion: refused
+    com, _ = ctx.commit(d)
+    ctx.synchronize()
+    d2 = d.clone()
+    d[5] += 1
+    torch.cuda.synchronize()
+    with pytest.raises(cabi.ZipError):
+        com.download()
+    com.free()
+    # 5. a HOST witness is copied by the commit: completing its handle never looks at the caller's array again
+    host = evals.copy()
+    com, _ = ctx.commit(host)
+    host[:] = 0
+    rows, _, _ = com.download()
+    assert np.array_equal(rows, rows_o)
+    com.free()
+    # 6. switched off: a plain commit stores everything again
+    ctx.set_speculation(False)
+    ctx.profile_read()
+    com, _ = ctx.commit(d2)
+    rows, _, _ = com.download()
+    assert np.array_equal(rows, rows_o) and ctx.profile_read()["raa_commit_kernel"][0] == 1
+    com.free()
+
+
 def _device_bytes(ptr, n):
     """n bytes at device address ptr (device 0) -> numpy, through a zero-copy torch view"""
     import torch

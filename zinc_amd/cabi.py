@@ -25,7 +25,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 
 EXPORTED_SYMBOLS = (
     "zip_abi_version", "zip_strerror", "zip_device_count", "zip_release_cached_memory", "zip_host_register", "zip_host_unregister", "zip_ctx_create", "zip_ctx_destroy",
-    "zip_ctx_last_error", "zip_ctx_synchronize", "zip_ctx_stream", "zip_commit", "zip_commit_hinted", "zip_commit_open", "zip_commit_open_begin", "zip_job_wait", "zip_commitment_free",
+    "zip_ctx_last_error", "zip_ctx_synchronize", "zip_ctx_stream", "zip_ctx_set_speculation", "zip_commit", "zip_commit_hinted", "zip_commit_open", "zip_commit_open_begin", "zip_job_wait", "zip_commitment_free",
     "zip_commitment_device_ptrs", "zip_commit_download", "zip_commitment_upload", "zip_open_testing",
     "zip_open_columns", "zip_open_eval", "zip_proof_len", "zip_open", "zip_sum_partials", "zip_merkle_trees",
     "zip_ctx_set_profiling", "zip_ctx_profile_read", "zip_ctx_commit_clock",
@@ -487,6 +487,10 @@ class ZipContext:
 
     def set_profiling(self, on=True):
         self._check(lib().zip_ctx_set_profiling(self._h, int(on)), "zip_ctx_set_profiling")
+
+    def set_speculation(self, on=True):
+        """zip_ctx_set_speculation: plain commits hint themselves with the columns of the ctx's last opening (default on)."""
+        self._check(lib().zip_ctx_set_speculation(self._h, int(on)), "zip_ctx_set_speculation")
 
     def profile_read(self):
         buf = (KernelTime * 32)()

@@ -1027,6 +1027,26 @@ __global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
     stamp_clock(a, 1);
 }
 
+// Digest of a witness (zip_commit's speculative hint, zip_hip.hip): out[0] += sum w[i], out[1] += sum w[i] * (2 i + 1),
+// both mod 2^64.  Not cryptographic: it guards against a caller that overwrote its DEVICE witness between a commit and
+// the transparent re-run of that commit -- any single changed word changes out[0], a permuted array changes out[1].
+__global__ void __launch_bounds__(256) witness_digest_kernel(const uint64_t *w, uint64_t n, unsigned long long *out) {
+    unsigned long long a = 0, b = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long v = w[i];
+        a += v;
+        b += v * (2ull * i + 1ull);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off, 64);
+        b += __shfl_down(b, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out, a);
+        atomicAdd(out + 1, b);
+    }
+}
+
 // [n][2] compact row entries (w0, w1, w2, sign as four 32-bit words) -> [n][4] Int<4> limbs
 __global__ void __launch_bounds__(256) expand_rows_kernel(const uint4 *in, uint4 *out, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {

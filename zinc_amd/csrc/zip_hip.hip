@@ -86,6 +86,11 @@ struct HintPlan {
     }
 };
 
+static inline bool speculation_default_flag() {
+    const char *e = getenv("ZIP_HIP_SPECULATE");
+    return !(e && atoi(e) == 0);
+}
+
 struct zip_ctx {
     zip_params p{};
     uint32_t depth = 0;
@@ -114,6 +119,8 @@ struct zip_ctx {
     std::shared_ptr<bool> alive = std::make_shared<bool>(true);  // false once zip_ctx_destroy has run
     bool profile_commit_only = false;  // zip_ctx_set_profiling(ctx, 2)
     std::shared_ptr<HintPlan> hint_plan;  // what the last hinted commit derived from its column list (memo)
+    bool speculate = speculation_default_flag();  // zip_commit hints itself with the columns of the ctx's last opening
+    bool seen_columns = false;                    // ... once an opening (or an explicit hint) has named some
     // chunk arrival counters of the persistent commit kernel: kRingSlots zeroed blocks of kRingStride counters, handed
     // out in turn; every kRingSlots commits the ring is zeroed again (ring_epoch moves: an older handle's counters
     // are gone, its openings then wait for the whole commit instead)
@@ -181,6 +188,11 @@ struct zip_commitment {
     unsigned char *hint_h = nullptr;  // pinned staging of the bitmaps (returns to ctx->hint_free)
     uint32_t *need_d = nullptr;       // device bitmaps (CommitArgs.need)
     const int64_t *evals_ref = nullptr;
+    // zip_commit's SPECULATIVE hint (the ctx's last column list): the caller never promised to keep a DEVICE witness
+    // unchanged, so its digest is taken beside the commit kernel and checked before a re-run reads evals_ref again
+    bool speculative = false;
+    unsigned long long *digest_d = nullptr;  // [2], pool block
+    hipEvent_t digest_done = nullptr;
     CommitArgs args{};                // the launch, for the re-run
     uint32_t grid = 0;
 };
@@ -2179,9 +2191,47 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
     return ZIP_OK;
 }
 
+static int32_t launch_witness_digest(zip_ctx *ctx, const int64_t *evals_d, size_t n, unsigned long long *out_d, hipStream_t st);
+
+// The two calls of an UNCHANGED ZincProver (src/zinc/prover.rs:315-320: commit, then open on a fresh PcsTranscript):
+// the commit cannot be told the columns, but in that flow they never change -- they are a function of the field and
+// the codeword length -- so a ctx that has seen an opening hints its next plain commits with THAT column list.  The
+// open that follows finds exactly what it reads (byte-identical proof, the hinted commit's speed); anything else asked
+// of the handle completes it first, transparently (rematerialize).  zip_ctx_set_speculation(ctx, 0) or
+// ZIP_HIP_SPECULATE=0 switches it off.
 int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
                    int32_t with_merkle, uint8_t *roots_out, zip_commitment **out) {
-    return commit_impl(ctx, evals, n_evals, evals_kind, with_merkle, nullptr, 0, roots_out, out);
+    if (!ctx || !out) return ZIP_ERR_NULL;
+    std::shared_ptr<HintPlan> plan;
+    {
+        std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
+        if (with_merkle && ctx->speculate && ctx->seen_columns && ctx->hint_plan && ctx->hint_plan->cw == ctx->p.codeword_len &&
+            !ctx->hint_plan->cols.empty() && commit_supports_hint(ctx->p.codeword_len))
+            plan = ctx->hint_plan;
+    }
+    if (!plan) return commit_impl(ctx, evals, n_evals, evals_kind, with_merkle, nullptr, 0, roots_out, out);
+    int32_t rc = commit_impl(ctx, evals, n_evals, evals_kind, 1, plan->cols.data(), (uint32_t)plan->cols.size(), roots_out, out);
+    if (rc) return rc;
+    zip_commitment *c = *out;
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
+    c->speculative = true;
+    if (c->hinted && !c->evals && c->evals_ref) {  // a DEVICE witness of the caller's: its digest, beside the commit kernel
+        if (pool_alloc(ctx, 16, (void **)&c->digest_d) == ZIP_OK) {
+            const size_t n = (size_t)ctx->rows_local * ctx->p.row_len;
+            if (launch_witness_digest(ctx, c->evals_ref, n, c->digest_d, ctx->s_aux) == ZIP_OK) {
+                c->digest_done = take_dep_event(ctx);
+                (void)hipEventRecord(c->digest_done, ctx->s_aux);
+            }
+        }
+    }
+    return ZIP_OK;
+}
+
+int32_t zip_ctx_set_speculation(zip_ctx *ctx, int32_t on) {
+    if (!ctx) return ZIP_ERR_NULL;
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
+    ctx->speculate = on != 0;
+    return ZIP_OK;
 }
 
 int32_t zip_commit_hinted(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
@@ -2198,7 +2248,17 @@ int32_t zip_commit_hinted(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zi
 
 // A hinted commitment is asked for something its kernel did not store: run the commit again, in full, into the
 // same buffers (same witness, same tables: the same bits where they already exist), and wait for it.
-static int32_t rematerialize(zip_commitment *c) {
+static int32_t launch_witness_digest(zip_ctx *ctx, const int64_t *evals_d, size_t n, unsigned long long *out_d, hipStream_t st) {
+    HIP_TRY(ctx, hipMemsetAsync(out_d, 0, 16, st));
+    const uint32_t blocks = (uint32_t)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL(witness_digest_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, reinterpret_cast<const uint64_t *>(evals_d),
+                       (uint64_t)n, out_d);
+    HIP_TRY(ctx, hipGetLastError());
+    return ZIP_OK;
+}
+
+// `evals_now`: the witness as the CURRENT call was handed it (zip_open gets the polynomial again), or null
+static int32_t rematerialize(zip_commitment *c, const int64_t *evals_now = nullptr) {
     if (!c->hinted) return ZIP_OK;
     zip_ctx *ctx = c->ctx;
     CommitArgs a = c->args;
@@ -2206,7 +2266,25 @@ static int32_t rematerialize(zip_commitment *c) {
     a.pk = nullptr;
     a.clock = nullptr;
     a.chunk_done = nullptr;  // the chunks of the first run stay published
-    a.evals = c->evals ? c->evals : c->evals_ref;
+    a.evals = evals_now ? evals_now : c->evals ? c->evals : c->evals_ref;
+    if (a.evals == c->evals_ref && !c->evals && c->speculative && c->digest_d) {
+        // the caller's device array, read a second time without the caller having been told it would be: has it changed?
+        const size_t n = (size_t)ctx->rows_local * ctx->p.row_len;
+        Scratch again(ctx);
+        int32_t rc = again.get(16);
+        if (rc) return rc;
+        if (c->digest_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, c->digest_done, 0));
+        if ((rc = launch_witness_digest(ctx, c->evals_ref, n, again.as<unsigned long long>(), ctx->stream))) return rc;
+        unsigned long long then_[2] = {0, 0}, now_[2] = {1, 1};
+        HIP_TRY(ctx, hipMemcpyAsync(then_, c->digest_d, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(now_, again.ptr, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, stream_wait(ctx->stream));
+        if (then_[0] != now_[0] || then_[1] != now_[1])
+            return fail(ctx, ZIP_ERR_INVALID_PARAM,
+                        "the device witness of this commitment has changed since zip_commit: the handle only holds what an "
+                        "opening of the ctx's usual columns reads (speculative hint) and cannot be completed any more; keep the "
+                        "witness until the handle is freed, or switch the speculation off (zip_ctx_set_speculation)");
+    }
     if (c->done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_commit, c->done, 0));
     HIP_TRY(ctx, stream_wait(ctx->stream));  // nobody still gathers from the buffers
     int32_t rc = dispatch_commit<true>(ctx, a, c->grid, ctx->s_commit);
@@ -2219,17 +2297,25 @@ static int32_t rematerialize(zip_commitment *c) {
 }
 
 // every column of cols[] lies inside the hint (host check); otherwise the handle is completed first
-static int32_t ensure_columns(zip_commitment *c, const uint32_t *cols, uint32_t n_cols) {
+static int32_t ensure_columns(zip_commitment *c, const uint32_t *cols, uint32_t n_cols, const int64_t *evals_now = nullptr) {
     if (!c->hinted) return ZIP_OK;
     // ... a packed handle serves the openings it was hinted with, in their order (rank_d); anything else completes it
     if (c->packed)
         return (c->plan && c->plan->cols.size() == n_cols && (n_cols == 0 || !memcmp(c->plan->cols.data(), cols, (size_t)n_cols * 4)))
-                   ? ZIP_OK : rematerialize(c);
+                   ? ZIP_OK : rematerialize(c, evals_now);
     for (uint32_t i = 0; i < n_cols; i++) {
         const uint32_t col = cols[i];
-        if ((col >> 5) >= c->hint_cols.size() || !((c->hint_cols[col >> 5] >> (col & 31)) & 1u)) return rematerialize(c);
+        if ((col >> 5) >= c->hint_cols.size() || !((c->hint_cols[col >> 5] >> (col & 31)) & 1u)) return rematerialize(c, evals_now);
     }
     return ZIP_OK;
+}
+
+// An opening names the columns this ctx's prover squeezes: the next plain zip_commit hints itself with them.
+static void note_columns(zip_ctx *ctx, const uint32_t *cols, uint32_t n_cols) {
+    if (!ctx->speculate || !n_cols || !commit_supports_hint(ctx->p.codeword_len)) return;
+    static const bool no_compact = getenv("ZIP_HIP_NO_COMPACT_ROWS") != nullptr;
+    (void)get_hint_plan(ctx, cols, n_cols, !no_compact && packed_enabled());
+    ctx->seen_columns = true;
 }
 
 void zip_commitment_free(zip_commitment *c) {
@@ -2244,6 +2330,11 @@ void zip_commitment_free(zip_commitment *c) {
     for (hipEvent_t e : c->aux) c->ctx->dep_event_pool.push_back(e);
     if (c->ctx->stream && !c->consumers_done) (void)stream_wait(c->ctx->stream);
     if (!c->ring_slot) pool_release(c->ctx, c->chunk_done);
+    if (c->digest_done) {
+        (void)event_wait(c->digest_done);
+        c->ctx->dep_event_pool.push_back(c->digest_done);
+    }
+    pool_release(c->ctx, c->digest_d);
     pool_release(c->ctx, c->need_d);
     if (c->hint_h) c->ctx->hint_free.push_back(c->hint_h);
     pool_release(c->ctx, c->rows);
@@ -2626,7 +2717,8 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
         out_d = res.as<uint8_t>();
     }
     if ((rc = check_cols(ctx, cols, n_cols))) return rc;
-    if ((rc = ensure_columns(c, cols, n_cols))) return rc;
+    if ((rc = ensure_columns(c, cols, n_cols, evals_d))) return rc;
+    note_columns(ctx, cols, n_cols);
     if ((rc = open_device(c, evals_d, coeffs, cols, n_cols, q0_mont, hf, out_d))) return rc;
     if (out_kind == ZIP_MEM_HOST) return deliver(ctx, proof_out, ZIP_MEM_HOST, out_d, total);
     return ZIP_OK;
@@ -3399,7 +3491,6 @@ int32_t zip_open_stream(zip_commitment *c, const int64_t *evals, zip_mem_kind ev
     const bool single = ctx->p.num_rows == 1;
     if (!single && (!coeffs || !q0_mont)) return fail(ctx, ZIP_ERR_NULL, "coeffs / q0_mont is NULL");
     if ((rc = check_cols(ctx, cols, n_cols))) return rc;
-    if ((rc = ensure_columns(c, cols, n_cols))) return rc;
     Scratch ev(ctx), ends(ctx), small(ctx), dev0(ctx), dev1(ctx);
     const int64_t *evals_d = c->evals;
     if (evals) {
@@ -3407,6 +3498,8 @@ int32_t zip_open_stream(zip_commitment *c, const int64_t *evals, zip_mem_kind ev
     } else if (!evals_d) {
         return fail(ctx, ZIP_ERR_NULL, "evals is NULL and the commitment retains no witness");
     }
+    if ((rc = ensure_columns(c, cols, n_cols, evals_d))) return rc;
+    note_columns(ctx, cols, n_cols);
     const size_t u_bytes = single ? 0 : (size_t)ctx->p.row_len * ctx->p.m_limbs * 8;
     const size_t row_bytes = (size_t)ctx->p.row_len * hf.fl * 8;
     const size_t colb = column_bytes(ctx);
