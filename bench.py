@@ -323,8 +323,10 @@ def main():
 
     def step():
         if rows_mode:
-            com, _roots = sharded.commit(evals_d)
+            # hinted commit enqueued, the shard's open pipelined behind it, the roots all-gathered at the end
+            com, _ = sharded.commit(evals_d, cols, gather_roots=False)
             sharded.open(com, evals_d, coeffs, cols, q0, zf)
+            sharded.gather_roots(com)
         else:
             if args.two_calls or args.no_hint:
                 # asynchronous: the open below overlaps it.  --no-hint: plain zip_commit, everything stored

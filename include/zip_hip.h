@@ -198,6 +198,17 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
                  const uint32_t *cols, uint32_t n_cols, const uint64_t *q0_mont, const zip_field *field,
                  uint8_t *proof_out, zip_mem_kind out_kind);
 
+/* The open of ONE ROW SHARD in one call (ctx created with row_begin / row_count; SURVEY.md 8e, one process per GPU):
+ * one pass over the shard's rows of the witness for BOTH partial row combinations -- partial u' (row_len * m_limbs
+ * u64) and partial evaluation row (row_len * limbs u64, Montgomery limbs) over the shard's rows, to be all-gathered
+ * and added with zip_sum_partials -- and the shard's rows of every opened column in wire order
+ * ([n_cols][row_count * 32 B values | row_count records]), pipelined behind the shard's commit kernel.
+ * coeffs / q0_mont: the shard's slices (row_count entries), HOST; everything else DEVICE.  Returns when the device work
+ * has finished. */
+int32_t zip_open_shard(zip_commitment *c, const int64_t *evals_d, const int64_t *coeffs, const uint32_t *cols, uint32_t n_cols,
+                       const uint64_t *q0_mont, const zip_field *field, uint64_t *uprime_part_d, uint64_t *row_part_d,
+                       uint8_t *wire_d);
+
 /* commit + open in ONE call: what ZincProver::commit_z_mle_and_prove_evaluation (src/zinc/prover.rs:305-328) does with
  * its two calls, commit (commit.rs:50-87) and open (open_z.rs:22-40) on a fresh PcsTranscript -- the binding for that
  * function body.  Same roots and byte-identical proof stream as zip_commit followed by zip_open; internally

@@ -81,12 +81,9 @@ def main():
     sharded = RowShardedZip(nv, zfull.perm1, zfull.perm2, backend=backend)
     assert (sharded.row_begin, sharded.row_count) == (begin, count)
 
-    com, roots_all = sharded.commit(sharded.local_slice(evals))
     point = orc.point_to_field(f, [1] * nv)
     rows_o, layers_o, roots_o = zfull.commit(evals)
     proof_o, cols, coeffs = zfull.open(f, evals, rows_o, layers_o, point, orc.new_transcript())
-    assert np.array_equal(roots_all.cpu().numpy(), roots_o), "all-gathered roots differ"
-
     lr = zfull.num_rows.bit_length() - 1
     q0 = orc.build_eq_x_r(f, point[nv - lr:])
 
@@ -94,7 +91,17 @@ def main():
         limbs = 4
 
     field = cabi.make_field(MODULUS, 4) if hip else _F()
-    uprime, row, wire = sharded.open(com, sharded.local_slice(evals), coeffs, cols, q0, field)
+    if hip:
+        # the prover's order: the columns are known before the commit (hinted commit, enqueued), the shard's open is
+        # pipelined behind it (zip_open_shard: one witness pass), the roots are all-gathered at the end
+        com, none = sharded.commit(sharded.local_slice(evals), cols, gather_roots=False)
+        assert none is None
+        uprime, row, wire = sharded.open(com, sharded.local_slice(evals), coeffs, cols, q0, field)
+        roots_all = sharded.gather_roots(com)
+    else:
+        com, roots_all = sharded.commit(sharded.local_slice(evals))
+        uprime, row, wire = sharded.open(com, sharded.local_slice(evals), coeffs, cols, q0, field)
+    assert np.array_equal(roots_all.cpu().numpy(), roots_o), "all-gathered roots differ"
     uprime, row, wire = uprime.cpu(), row.cpu(), wire.cpu()
     wires = [torch.empty_like(wire) for _ in range(world)]
     dist.all_gather(wires, wire)

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = (
     "zip_abi_version", "zip_strerror", "zip_device_count", "zip_release_cached_memory", "zip_host_register", "zip_host_unregister", "zip_ctx_create", "zip_ctx_destroy",
     "zip_ctx_last_error", "zip_ctx_synchronize", "zip_ctx_stream", "zip_ctx_set_speculation", "zip_commit", "zip_commit_hinted", "zip_commit_open", "zip_commit_open_begin", "zip_job_wait", "zip_commitment_free",
     "zip_commitment_device_ptrs", "zip_commit_download", "zip_commitment_upload", "zip_open_testing",
-    "zip_open_columns", "zip_open_eval", "zip_proof_len", "zip_open", "zip_sum_partials", "zip_merkle_trees",
+    "zip_open_columns", "zip_open_eval", "zip_proof_len", "zip_open", "zip_open_shard", "zip_sum_partials", "zip_merkle_trees",
     "zip_ctx_set_profiling", "zip_ctx_profile_read", "zip_ctx_commit_clock",
     "zip_mctx_create", "zip_mctx_destroy", "zip_mctx_last_error", "zip_mctx_shards", "zip_mctx_shard_ctx", "zip_mctx_set_witness",
     "zip_mctx_commit_open", "zip_mctx_shard_openings", "zip_mctx_ends", "zip_mctx_roots", "zip_mctx_roots_path", "zip_verify", "zip_mle_eval", "zip_commitment_mle_eval", "zip_field_map_int256",
@@ -222,6 +222,8 @@ def lib():
     L.zip_proof_len.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.zip_proof_len.restype = C.c_size_t
     L.zip_open.argtypes = [vp, i64p, C.c_int, i64p, u32p, C.c_uint32, u64p, C.POINTER(ZipField), u8p, C.c_int]
+    L.zip_open_shard.argtypes = [vp, i64p, i64p, u32p, C.c_uint32, u64p, C.POINTER(ZipField), u64p, u64p, u8p]
+    L.zip_open_shard.restype = C.c_int32
     L.zip_sum_partials.argtypes = [vp, u64p, u64p, C.c_uint32, C.POINTER(ZipField), u64p, u64p]
     L.zip_merkle_trees.argtypes = [C.c_int32, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u8p]
     L.zip_ctx_set_profiling.argtypes = [vp, C.c_int32]
@@ -657,6 +659,18 @@ class Commitment:
                                    cols.ctypes.data, cols.size, q0.ctypes.data if q0 is not None else None,
                                    C.byref(field), cb, None, chunk_bytes)
         c._check(rc, "zip_open_stream")
+
+    def open_shard(self, evals_d, coeffs, cols, q0_mont, field: ZipField, uprime_part, row_part, wire):
+        """zip_open_shard: both partial row combinations (one witness pass) + this shard's rows of every opened column;
+        evals_d / outputs are device tensors, coeffs / q0_mont the shard's host slices."""
+        c = self.ctx
+        cols = np.ascontiguousarray(cols, dtype=np.uint32)
+        coeffs_c = np.ascontiguousarray(coeffs, dtype=np.int64) if coeffs is not None else None
+        q0 = np.ascontiguousarray(q0_mont, dtype=np.uint64) if q0_mont is not None else None
+        rc = lib().zip_open_shard(self._h, _ptr(evals_d)[0], coeffs_c.ctypes.data if coeffs_c is not None else None,
+                                  cols.ctypes.data, cols.size, q0.ctypes.data if q0 is not None else None, C.byref(field),
+                                  _ptr(uprime_part)[0] if uprime_part is not None else None, _ptr(row_part)[0], _ptr(wire)[0])
+        c._check(rc, "zip_open_shard")
 
     def open(self, evals, coeffs, cols, q0_mont, field: ZipField, out=None):
         """Whole proof stream of MultilinearZip::open (the field elements still need absorbing)."""

@@ -2724,6 +2724,50 @@ int32_t zip_open(zip_commitment *c, const int64_t *evals, zip_mem_kind evals_kin
     return ZIP_OK;
 }
 
+// The open of ONE ROW SHARD in one call (what zip_mctx does per shard, for the one-process-per-GPU arrangement of
+// zinc_amd/dist.py): one pass over the shard's witness rows for both partial row combinations, and the shard's rows of
+// every opened column, pipelined behind its commit kernel.  Everything DEVICE memory, asynchronous on the ctx's stream
+// except the small host inputs (consumed on return: the call synchronises the stream once).
+int32_t zip_open_shard(zip_commitment *c, const int64_t *evals_d, const int64_t *coeffs, const uint32_t *cols, uint32_t n_cols,
+                       const uint64_t *q0_mont, const zip_field *field, uint64_t *uprime_part_d, uint64_t *row_part_d,
+                       uint8_t *wire_d) {
+    if (!c || !evals_d || !wire_d || !row_part_d || (n_cols && !cols)) return ZIP_ERR_NULL;
+    zip_ctx *ctx = c->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
+    if (!c->layers) return fail(ctx, ZIP_ERR_INVALID_PARAM, "commitment has no Merkle trees (commit_no_merkle)");
+    HostField hf;
+    int32_t rc;
+    if ((rc = make_field(ctx, field, &hf))) return rc;
+    const bool single = ctx->p.num_rows == 1;
+    if (!single && (!coeffs || !q0_mont || !uprime_part_d)) return fail(ctx, ZIP_ERR_NULL, "coeffs / q0_mont / uprime_part is NULL");
+    if ((rc = check_cols(ctx, cols, n_cols))) return rc;
+    if ((rc = ensure_columns(c, cols, n_cols, evals_d))) return rc;
+    Scratch small(ctx);
+    CombineScratch cscr(ctx);
+    SmallInputs si;
+    if (!single) {
+        si.src[0] = coeffs;
+        si.bytes[0] = (size_t)ctx->rows_local * 8;
+    }
+    si.src[1] = single ? hf.r : q0_mont;
+    si.bytes[1] = (size_t)ctx->rows_local * hf.fl * 8;
+    si.src[2] = cols;
+    si.bytes[2] = (size_t)n_cols * 4;
+    unsigned char *sb;
+    if ((rc = stage_small(ctx, si, small, &sb))) return rc;
+    const uint32_t *cols_dv = reinterpret_cast<const uint32_t *>(sb + si.off[2]);
+    CombineOut o{};
+    o.uprime = single ? nullptr : uprime_part_d;
+    o.row_limbs = row_part_d;
+    const int64_t *coeffs_dv = reinterpret_cast<const int64_t *>(sb + si.off[0]);
+    const uint64_t *q0_dv = reinterpret_cast<const uint64_t *>(sb + si.off[1]);
+    if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o, nullptr, &cscr, 1))) return rc;
+    if ((rc = run_open_columns_pipelined(c, cols_dv, n_cols, wire_d))) return rc;
+    if ((rc = run_combine(ctx, evals_d, coeffs_dv, q0_dv, &hf, !single, true, o, nullptr, &cscr, 2))) return rc;
+    return recover_gather_timeout(c, cols_dv, n_cols, wire_d);  // (synchronises the stream)
+}
+
 int32_t zip_commit_open(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind, const int64_t *coeffs,
                         const uint32_t *cols, uint32_t n_cols, const uint64_t *q0_mont, const zip_field *field,
                         uint8_t *roots_out, uint8_t *proof_out, zip_mem_kind out_kind, zip_commitment **out) {

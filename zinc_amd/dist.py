@@ -55,14 +55,30 @@ class HipBackend:
         c = self.ctx
         return c.row_len, c.num_rows, c.codeword_len, c.depth
 
-    def commit(self, evals):
-        com, _ = self.ctx.commit(evals, want_roots=False)
+    def commit(self, evals, cols=None):
+        """Asynchronous: the persistent commit kernel is enqueued and the handle returned; `roots(com)` waits for it.
+        cols: the columns the open will ask for (known before the commit in the prover's flow): a hinted commit."""
+        com, _ = self.ctx.commit(evals, want_roots=False, hint_cols=cols)
+        return com
+
+    def roots(self, com):
+        """This shard's roots as a device tensor, once its commit kernel has finished."""
         roots_ptr = com.roots_ptr()
         self.ctx.synchronize()
         holder = type("_H", (), {})()
         holder.__cuda_array_interface__ = {"shape": (self.ctx.rows_local, 32), "typestr": "|u1",
                                            "data": (roots_ptr, False), "version": 2}
-        return com, self.torch.as_tensor(holder, device=self.device)
+        return self.torch.as_tensor(holder, device=self.device)
+
+    def open_shard(self, com, evals, coeffs, cols, q0, field, upart, fpart):
+        """One call: both partial row combinations in ONE witness pass + this shard's rows of every opened column,
+        pipelined behind the commit kernel (zip_open_shard)."""
+        wire = self.torch.empty(len(cols) * self.ctx.rows_local * (32 + 8 + 32 * self.ctx.depth), dtype=self.torch.uint8,
+                                device=self.device)
+        if isinstance(evals, np.ndarray):  # the entry point takes the shard's witness rows in device memory
+            evals = self.torch.from_numpy(np.ascontiguousarray(evals, dtype=np.int64)).to(self.device)
+        com.open_shard(evals, coeffs, cols, q0, field, upart, fpart, wire)
+        return wire
 
     def empty(self, shape, dtype):
         return self.torch.empty(shape, dtype=dtype, device=self.device)
@@ -123,10 +139,20 @@ class RowShardedZip:
             self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
         return out.reshape((self.world,) + tuple(t.shape))
 
-    def commit(self, evals_local):
-        """-> (local commitment handle, roots of ALL rows [num_rows, 32] on every rank)."""
-        com, roots_local = self.backend.commit(evals_local)
+    def commit(self, evals_local, cols=None, gather_roots=True):
+        """-> (local commitment handle, roots of ALL rows [num_rows, 32] on every rank).
+        cols: the opening's columns when they are known before the commit (prover.rs:316): a hinted commit.
+        gather_roots=False returns (handle, None) at once -- the commit kernel keeps running, an open enqueued now is
+        pipelined behind it -- and `gather_roots(com)` collects the commitment afterwards."""
+        if hasattr(self.backend, "roots"):
+            com = self.backend.commit(evals_local, cols)
+            return com, (self.gather_roots(com) if gather_roots else None)
+        com, roots_local = self.backend.commit(evals_local)  # (a test backend: synchronous)
         return com, self._all_gather(roots_local).reshape(self.num_rows, 32)
+
+    def gather_roots(self, com):
+        """The one exchange of the commit: every rank's roots, all-gathered (RCCL over xGMI)."""
+        return self._all_gather(self.backend.roots(com)).reshape(self.num_rows, 32)
 
     def open(self, com, evals_local, coeffs, cols, q0_mont, field):
         """coeffs / q0_mont: the FULL challenge vectors (every rank derives the same transcript).
@@ -136,9 +162,13 @@ class RowShardedZip:
         fl = field.limbs
         upart = self.backend.empty((self.row_len, 8), t.int64)
         fpart = self.backend.empty((self.row_len, fl), t.int64)
-        self.backend.open_testing(evals_local, np.ascontiguousarray(coeffs[sl]), upart)
-        self.backend.open_eval(evals_local, np.ascontiguousarray(q0_mont[sl]), field, fpart)
-        wire = self.backend.open_columns(com, cols)
+        if hasattr(self.backend, "open_shard"):  # one call: one witness pass, openings pipelined behind the commit
+            wire = self.backend.open_shard(com, evals_local, np.ascontiguousarray(coeffs[sl]), cols,
+                                           np.ascontiguousarray(q0_mont[sl]), field, upart, fpart)
+        else:
+            self.backend.open_testing(evals_local, np.ascontiguousarray(coeffs[sl]), upart)
+            self.backend.open_eval(evals_local, np.ascontiguousarray(q0_mont[sl]), field, fpart)
+            wire = self.backend.open_columns(com, cols)
         uall, fall = self._all_gather(upart), self._all_gather(fpart)
         uprime = self.backend.empty((self.row_len, 8), t.int64)
         row = self.backend.empty((self.row_len, fl), t.int64)
