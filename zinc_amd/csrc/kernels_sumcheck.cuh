@@ -14,6 +14,7 @@
 // give the same evaluations as the reference's Rayon fold in any order.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "kernels_open.cuh"
@@ -97,6 +98,15 @@ __device__ __forceinline__ void acc_wide_reduce(uint64_t (&acc)[2 * FL + 1], con
     reduce_wide<FL>(y, f, out);  // y mod q, canonical (y < 2^64 q << q R)
 }
 
+// f(integral_constant<int, E>) for E = FIRST .. LAST, unrolled by construction
+template <int FIRST, int LAST, class F>
+__device__ __forceinline__ void sc_static_for(F &&f) {
+    if constexpr (FIRST <= LAST) {
+        f(std::integral_constant<int, FIRST>{});
+        sc_static_for<FIRST + 1, LAST>(f);
+    }
+}
+
 template <int FL>
 struct SumcheckRoundArgs {
     const uint64_t *src[kSumcheckMaxMles];  // tables of this round's input (2*half entries, or 4*half when fold)
@@ -173,7 +183,10 @@ __global__ void __launch_bounds__(256) sumcheck_round_kernel(SumcheckRoundArgs<F
 #pragma unroll
             for (int i = 0; i < FL; i++) nxt[k][i] = v1[i];
         }
-        auto point = [&](const int e, const uint64_t (&val)[K][FL]) {
+        // (the evaluation point is a COMPILE-TIME index: behind a loop hipcc would not unroll -- K * DEG large -- the
+        // accumulators wacc[e] became a stack object, 288-368 bytes of scratch per lane in the CCS shapes)
+        auto point = [&](auto e_tag, const uint64_t (&val)[K][FL]) {
+            constexpr int e = decltype(e_tag)::value;
             uint64_t c[FL], w[2 * FL];  // the point's value = c * val[K - 1], added up unreduced
             if (a.n_terms == 0) {
 #pragma unroll
@@ -226,9 +239,9 @@ __global__ void __launch_bounds__(256) sumcheck_round_kernel(SumcheckRoundArgs<F
             mul_wide<FL>(c, val[K - 1], w);
             acc_wide_add<FL>(wacc[e], w);
         };
-        point(0, val);
-        if (DEG >= 1) point(1, nxt);
-        if (DEG >= 2) {
+        point(std::integral_constant<int, 0>{}, val);
+        if constexpr (DEG >= 1) point(std::integral_constant<int, 1>{}, nxt);
+        if constexpr (DEG >= 2) {
 #pragma unroll
             for (int k = 0; k < K; k++) {  // val <- step = v1 - v0
                 uint64_t d[FL];
@@ -238,12 +251,11 @@ __global__ void __launch_bounds__(256) sumcheck_round_kernel(SumcheckRoundArgs<F
 #pragma unroll
                 for (int i = 0; i < FL; i++) val[k][i] = d[i];
             }
-#pragma unroll
-            for (int e = 2; e <= DEG; e++) {
+            sc_static_for<2, DEG>([&](auto e_tag) {
 #pragma unroll
                 for (int k = 0; k < K; k++) fe_add<FL>(nxt[k], val[k], f);
-                point(e, nxt);
-            }
+                point(e_tag, nxt);
+            });
         }
     }
     uint64_t acc[DEG + 1][FL];
