@@ -126,7 +126,7 @@ def kernel_sources_sha():
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("kernels_commit.cuh", "kernels_open.cuh", "blake3.cuh"):
+    for name in ("kernels_commit.cuh", "kernels_open.cuh", "blake3.cuh", "blake3_sched.inc"):
         with open(os.path.join(ROOT, "zinc_amd", "csrc", name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -316,6 +316,8 @@ def main():
         ctx = cabi.ZipContext(nv, perm1, perm2, device=local_rank)
         per = num_rows
         witness = splitmix64(args.seed + 1000 * rank, n)
+    if args.no_hint:
+        ctx.set_speculation(False)  # everything stored, also after the first opening has named the columns
     evals_d = torch.from_numpy(np.ascontiguousarray(witness)).to(dev)
     if not rows_mode:
         proof = torch.empty(ctx.proof_len(n_cols, fl), dtype=torch.uint8, device=dev)

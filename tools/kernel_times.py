@@ -23,6 +23,8 @@ def main():
     args = ap.parse_args()
     import torch
 
+    # what is being measured: tools/pmc_summary.py reads this line back from the log of a counter pass
+    print("kernel_src_sha", bench.kernel_sources_sha(), flush=True)
     nv = args.num_vars
     row_len, num_rows, cw = cabi.geometry(nv)
     ctx = cabi.ZipContext(nv, shuffle_seeded_perm(1, cw), shuffle_seeded_perm(2, cw))
@@ -37,6 +39,7 @@ def main():
             if hinted == "one_call":
                 _, _, com = ctx.commit_open(evals, coeffs, cols, q0, zf, out=proof, want_roots=False, keep=True)
             else:
+                ctx.set_speculation(bool(hinted))  # (a "plain" commit must not hint itself with the last opening's columns)
                 com, _ = ctx.commit(evals, want_roots=False, hint_cols=cols if hinted else None)
                 if args.serial:
                     ctx.synchronize()

@@ -28,10 +28,24 @@ def kernel_sources_sha():
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("kernels_commit.cuh", "kernels_open.cuh", "blake3.cuh"):
+    for name in ("kernels_commit.cuh", "kernels_open.cuh", "blake3.cuh", "blake3_sched.inc"):
         with open(os.path.join(ROOT, "zinc_amd", "csrc", name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def measured_sha(d):
+    """The digest tools/kernel_times.py printed into the log of the counter pass itself (`<dir>.log`, written by
+    tools/profile_round.sh): what was MEASURED, not what the tree holds when the summary is written."""
+    if not d:
+        return None
+    try:
+        for line in open(d.rstrip("/") + ".log"):
+            if line.startswith("kernel_src_sha "):
+                return line.split()[1]
+    except OSError:
+        pass
+    return None
 
 
 def find(d, pattern):
@@ -62,10 +76,9 @@ def classify(kernel):
         args = k[k.index("<") + 1:k.index(">")].replace(" ", "").split(",")
         if args[1] != "true":  # encode only
             return None
-        if "raa_commit16" in k:  # <T, HASH, MASKED>
-            mode = "hinted" if (len(args) > 2 and args[2] == "true") else "plain"
-        else:  # <E, HASH, MODE>: 0 everything stored, 1 hinted at the natural places, 3 hinted and packed
-            mode = {"0": "plain", "1": "hinted", "3": "packed"}.get(args[2] if len(args) > 2 else "0", "plain")
+        # raa_commit_kernel<E, HASH, MODE> / raa_commit16_kernel<T, HASH, MODE>: MODE 0 everything stored, 1 hinted at
+        # the natural places, 3 hinted and packed
+        mode = {"0": "plain", "1": "hinted", "3": "packed"}.get(args[2] if len(args) > 2 else "0", "plain")
         return "raa_commit_kernel", mode
     if "open_columns_kernel" in k or "open_columns_stream_kernel" in k:
         return "open_columns_kernel", "any"
@@ -115,11 +128,18 @@ def main():
         print("\n".join(lines))
     fetch, write = pmc(a.fetch, "FETCH_SIZE"), pmc(a.write, "WRITE_SIZE")
     insts = pmc(a.sq, "SQ_INSTS_VALU")
+    active, wcyc = pmc(a.sq, "SQ_ACTIVE_INST_VALU"), pmc(a.sq, "SQ_WAVE_CYCLES")
+    shas = {x for x in (measured_sha(a.fetch), measured_sha(a.write), measured_sha(a.sq)) if x}
+    sha = shas.pop() if len(shas) == 1 else None  # (passes taken from different sources: no digest)
     if fetch or write or insts:
         lines = [f"# {tag}: per-launch counters from rocprofv3 --pmc (separate passes), num_vars = {a.num_vars}", "",
                  "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; how to read FETCH_SIZE for each access pattern",
-                 f"is measured in `{a.tag}_fetch_calibration.md`.  SQ_INSTS_VALU = VALU wave-instructions issued.", "",
-                 "| kernel | launches | FETCH_SIZE KiB | WRITE_SIZE KiB | SQ_INSTS_VALU |", "|---|---|---|---|---|"]
+                 f"is measured in `{a.tag}_fetch_calibration.md`.  SQ_INSTS_VALU = VALU wave-instructions issued;",
+                 "SQ_ACTIVE_INST_VALU = quad-cycles a VALU instruction was executing, SQ_WAVE_CYCLES = quad-cycles of wave",
+                 "residency (both summed over waves); `VALU busy while resident` = ACTIVE_INST_VALU / (WAVE_CYCLES / waves per SIMD)",
+                 "for the commit kernel's 4 waves per SIMD.  Kernel sources measured: " + (f"`{sha}`" if sha else "(not recorded)") + ".", "",
+                 "| kernel | launches | FETCH_SIZE KiB | WRITE_SIZE KiB | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU | SQ_WAVE_CYCLES | VALU busy while resident (4 waves/SIMD) |",
+                 "|---|---|---|---|---|---|---|---|"]
         path = os.path.join(prof, "pmc_traffic.json")
         try:
             traffic = json.load(open(path))
@@ -128,12 +148,17 @@ def main():
         for k in sorted(set(fetch) | set(write) | set(insts)):
             fk, wk, ik = avg(fetch.get(k, [])), avg(write.get(k, [])), avg(insts.get(k, []))
             n = max(len(fetch.get(k, [])), len(write.get(k, [])), len(insts.get(k, [])))
-            lines.append(f"| `{k[:80]}` | {n} | {fk:,.0f} | {wk:,.0f} | {ik:,.0f} |")
+            ak, ck = avg(active.get(k, [])), avg(wcyc.get(k, []))
+            busy = f"{ak / (ck / 4):.3f}" if (ck and "raa_commit" in k) else ""
+            lines.append(f"| `{k[:80]}` | {n} | {fk:,.0f} | {wk:,.0f} | {ik:,.0f} | {ak:,.0f} | {ck:,.0f} | {busy} |")
             cl = classify(k)
             if cl:
                 traffic[f"{cl[0]}:{a.num_vars}:{cl[1]}"] = {
                     "kernel": k[:120], "num_vars": a.num_vars, "mode": cl[1], "fetch_kib": fk, "write_kib": wk,
-                    "valu_insts": ik, "source": f"profiles/{tag}_pmc.md", "kernel_src_sha": kernel_sources_sha()}
+                    "valu_insts": ik, "valu_active_quadcycles": ak, "wave_quadcycles": ck, "source": f"profiles/{tag}_pmc.md",
+                    # the digest the counter pass itself printed (tools/kernel_times.py); None = not recorded at
+                    # measurement time: bench.py then reports the entry as stale
+                    "kernel_src_sha": sha}
         with open(os.path.join(prof, f"{tag}_pmc.md"), "w") as fh:
             fh.write("\n".join(lines) + "\n")
         with open(path, "w") as fh:
