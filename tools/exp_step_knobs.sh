@@ -1,17 +1,12 @@
 # GPU box: one bench line per knob setting (step time, kernel times per step, in-kernel clock)
 run() { echo "== $*"; env "$@" python3 bench.py --no-cpu-baseline --no-pipelined --steps 20 2>/dev/null | python3 -c "
-import json,sys;d=json.loads(sys.stdin.read());k=d['kernels_ms_per_step'];print(d['ms_per_step'], 'commit',k['raa_commit_kernel'],'gather',k['open_columns_kernel'],'combine',k['combine_rows_kernel'], 'clk', d['roofline_valu']['clock_mhz'])"; }
-export ZIP_HIP_GATHER_LEAN=0
+import json,sys;d=json.loads(sys.stdin.read());k=d['kernels_ms_per_step'];print(d['ms_per_step'], 'commit',k['raa_commit_kernel'],'gather',k['open_columns_kernel'],'combine',k['combine_rows_kernel'], 'clk', d['roofline_valu'] and d['roofline_valu']['clock_mhz'])"; }
 run A=1
-run ZIP_HIP_GATHER_STREAMS=1
-run A=1
-run ZIP_HIP_COMBINE=aux ZIP_HIP_COMBINE_PRIO=0
-run ZIP_HIP_COMBINE=aux
+run ZIP_HIP_GATHER_RPB=16
+run ZIP_HIP_GATHER_RPB=24
+run ZIP_HIP_CHUNK_ROUNDS=3,3,3,3,4
+run ZIP_HIP_CHUNK_ROUNDS=2,3,3,4,4
+run ZIP_HIP_CHUNK_ROUNDS=3,3,3,3,4 ZIP_HIP_GATHER_RPB=16
 run ZIP_HIP_CHUNK_ROUNDS=2,2,4,4,4
-run ZIP_HIP_CHUNK_ROUNDS=2,2,4,4,4 ZIP_HIP_COMBINE=aux ZIP_HIP_COMBINE_PRIO=0
-run ZIP_HIP_CHUNK_ROUNDS=2,3,3,4,4 ZIP_HIP_COMBINE=aux ZIP_HIP_COMBINE_PRIO=0
-run ZIP_HIP_CHUNK_ROUNDS=1,2,3,3,3,4 ZIP_HIP_COMBINE=aux ZIP_HIP_COMBINE_PRIO=0
-run ZIP_HIP_CHUNK_ROUNDS=2,2,2,2,2,2,2,2 ZIP_HIP_COMBINE=aux ZIP_HIP_COMBINE_PRIO=0
-run ZIP_HIP_CHUNK_ROUNDS=3,3,3,3,4 ZIP_HIP_COMBINE=aux ZIP_HIP_COMBINE_PRIO=0
-run ZIP_HIP_CHUNK_ROUNDS=2,2,4,4,3,1 ZIP_HIP_COMBINE=aux ZIP_HIP_COMBINE_PRIO=0
+run ZIP_HIP_CHUNK_ROUNDS=3,4,4,5
 run A=1

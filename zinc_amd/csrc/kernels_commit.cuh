@@ -354,7 +354,7 @@ __device__ __forceinline__ void bfly_hash(Src &src, uint32_t (&h)[8]) {
 //   rest   the remaining levels (6 .. depth), the roots, the release fence and the counter: AFTER the hash phase of
 //          the NEXT row, by the oldest wave of each SIMD (ChunkFinisher::after_hash); the chunk is published ~70 us
 //          later than before, which the consumer's slack absorbs.  The last chunk of the kernel has no next row: its
-//          rest runs at once, on wave 0.
+//          rest runs at once, the same way.
 // Stages hand their nodes over through global memory (L2): a storing wave waits for its stores (vmcnt(0)) before the
 // barrier or the LDS counter that the loading wave passes afterwards.
 // Levels [lvl, lvl + nl) (nl = 1 or 2) of the rows of rounds first .. first + nrows_c - 1 of this workgroup from their
@@ -443,19 +443,6 @@ struct ChunkFinisher {
         }
     }
 
-    // ONE wave, at once: the levels from `lvl` up, the roots, the publication (the last chunk of the kernel)
-    static __device__ __forceinline__ void tail(const CommitArgs &a, uint32_t first, uint32_t nrows_c, uint32_t lvl, uint32_t index,
-                                                uint32_t lane) {
-        const uint32_t cw = a.cw, depth = 31u - __builtin_clz(cw);
-        while (lvl <= depth) {
-            const uint32_t nl = depth - lvl >= 1u ? 2u : 1u;
-            upper_stage(a, first, nrows_c, lvl, nl, lane, 64u);
-            lvl += nl;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next stage loads what this one stored (same wave)
-        }
-        publish(a, index, lane);
-    }
-
     // this wave's stores are in L2: count it in
     static __device__ __forceinline__ void signal(uint32_t *flag, uint32_t lane) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -541,15 +528,14 @@ struct ChunkFinisher {
                 store_hash(a.roots + (size_t)r * 8, h);
             }
         }
-        if (last) {  // no next row to hide the rest behind
-            __syncthreads();
-            if (wave == 0) tail(a, first, nrows_c, lvl, cc.index, lane);
-        } else {
-            pending = true;
-            p_first = first;
-            p_nrows = nrows_c;
-            p_lvl = lvl;
-            p_index = cc.index;
+        pending = true;
+        p_first = first;
+        p_nrows = nrows_c;
+        p_lvl = lvl;
+        p_index = cc.index;
+        if (last) {  // no next row to hide the rest behind: the same staged hand-over between the oldest waves, at once
+            __syncthreads();  // (the head's stores are in L2: what top_of_row + a row's barriers do otherwise)
+            after_hash(a, wave, lane, T);
         }
     }
 };

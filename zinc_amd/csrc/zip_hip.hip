@@ -2038,6 +2038,15 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
                 }
                 if (!sched.empty() && used < rounds) sched.back() += rounds - used;
             }
+            // default from 12 rounds up (2^24: 16 rounds): chunks of three rounds, the remainder in the last one
+            // (3,3,3,3,4).  The chain of gathers is what ends a step (each takes about as long as the commit kernel
+            // needs for its chunk), so it should start early: against four chunks of four the first gather starts a
+            // round earlier; a fifth chunk end costs the commit kernel ~17 us.  1.849 against 1.859-1.872 ms per step.
+            if (sched.empty() && !ctx->n_chunks && rounds >= 12) {
+                const uint32_t n = std::min(8u, rounds / 3), base = rounds / n;
+                for (uint32_t k = 0; k + 1 < n; k++) sched.push_back(base);
+                sched.push_back(rounds - base * (n - 1));
+            }
         }
         uint64_t chunk_ends = 0;
         if (sched.empty()) {
