@@ -584,24 +584,20 @@ __global__ void __launch_bounds__(256) open_columns_stream_kernel(OpenColsArgs a
     }
 }
 
-// The openings with as little VALU work as they can be made with (round 3).  Beside the VALU-bound commit kernel a
-// gather pays for every vector-ALU instruction it issues with the hashing waves' time -- its loads, stores and scalar
-// instructions issue on other ports -- and open_columns_kernel / open_columns_stream_kernel spend ~100 VALU instructions
-// per wave and 32 rows on 64-bit pointer walks, loop counters held per lane and data selects (49.8 M per step at 2^24:
-// 6.5 % of the commit kernel's own, and that is what the commit kernel ran slower beside them).  Here:
-//   * one workgroup takes MANY rows of one opening (rows_per_block, 128 by default): the per-lane set-up -- role,
-//     node offset, rank look-up -- is paid once per 128 rows instead of once per 32;
-//   * the walk over the rows is two instructions per pass (one v_lshl_add_u64 each for the source and the destination
-//     pointer); the pass count is wave-uniform (scalar loop), the last partial pass is predicated once;
-//   * no data selects: the record header is its own lane role that only stores (8 bytes, a constant), the upper
-//     half of a compact row entry's Int<4> (the sign word four times) is four dword stores of the loaded sign word;
-//   * no LDS, no barrier: every lane moves its 16 bytes straight from the tree / the packed block to the stream
-//     (8-byte-aligned records: global_store_dwordx4 at dword alignment).
-// Lane roles of the SLOTS lanes reserved per row (h = lane % SLOTS):
-//   h < 2 depth      half (h & 1) of the level-(h >> 1) sibling            h == 2 depth + 1   value, low 16 bytes
-//   h == 2 depth     be64(depth), the record's first 8 bytes               h == 2 depth + 2   value, high 16 bytes
-struct __attribute__((packed, aligned(4))) oc_u32_a4 { uint32_t x; };
-
+// The openings with as few MEMORY INSTRUCTIONS as they can be made with (round 3, second attempt).  What a gather costs
+// the VALU-bound commit kernel beside it is its vector-memory and LDS instructions (~35 SIMD cycles of hashing each,
+// EXPERIMENTS.md), not its VALU ones: the first "lean" kernel (fewest VALU instructions, but split loads, an 8-byte
+// header store and four dword stores for a sign word: 32 memory instructions per wave and 32 rows) slowed the commit
+// kernel MORE than open_columns_kernel with its LDS image (16).  Here every lane that has a role issues exactly ONE
+// 16-byte load and ONE 16-byte store per row, nothing else: 8 memory instructions per wave and 32 rows.
+//   h < 2 depth      half (h & 1) of the level-(h >> 1) sibling: 16 bytes from the tree / the packed block to the record
+//   h == 2 depth     the record's first 16 bytes: be64(depth), then the first 8 bytes of the level-0 sibling -- it loads
+//                    what lane 0 loads (one request in the TA) and stores [header | low half]; lane 0 writes the same 8
+//                    bytes again
+//   h == 2 depth + 1 the value's low 16 bytes      h == 2 depth + 2: its high 16 bytes (a compact entry's sign word
+//                    four times: three register moves)
+// No LDS, no barrier; 8-byte-aligned records: global_store_dwordx4 at dword alignment; the walk over the rows is one
+// 64-bit add each for the source and the destination pointer; four rows in flight per lane.
 template <int SLOTS>
 __global__ void __launch_bounds__(256) open_columns_lean_kernel(OpenColsArgs a) {
     constexpr uint32_t K = 4;               // Int<4> column values (checked by zip_ctx_create)
@@ -619,7 +615,7 @@ __global__ void __launch_bounds__(256) open_columns_lean_kernel(OpenColsArgs a) 
     const uint32_t h = threadIdx.x & (SLOTS - 1), rsub = threadIdx.x / SLOTS;
     if (h > 2 * d + 2) return;
     const bool is_hdr = h == 2 * d, is_val = h > 2 * d;
-    const uint32_t half = is_val ? h - 2 * d - 1 : (h & 1u);
+    const uint32_t half = is_val ? h - 2 * d - 1 : is_hdr ? 0u : (h & 1u);
     const uint32_t lvl = (is_hdr || is_val) ? 0u : h >> 1;
     const uint32_t row = r0 + rsub;
     const bool val_hi_compact = is_val && half && a.compact_rows;
@@ -650,43 +646,22 @@ __global__ void __launch_bounds__(256) open_columns_lean_kernel(OpenColsArgs a) 
                           : base + (size_t)a.num_rows * 8 * K + (size_t)row * rec_bytes + (is_hdr ? 0u : 8u + h * 16u);
     const size_t dst_step = is_val ? (size_t)RPP * 8 * K : (size_t)RPP * rec_bytes;
     const uint64_t hdr = __builtin_bswap64((uint64_t)d);
+    const uint32_t hdr_lo = (uint32_t)hdr, hdr_hi = (uint32_t)(hdr >> 32);
     const uint32_t full = nrows / RPP, rest = nrows % RPP;  // wave-uniform: the loops below are scalar loops
-    // N passes at once: all loads first (N x 16 bytes in flight per lane), then the stores by role.  The N source and
-    // destination addresses are formed ONCE, ahead of the role branches.
     auto passes = [&](auto n_tag) {
         constexpr int N = decltype(n_tag)::value;
-        const uint8_t *sk[N];
-        uint8_t *dk[N];
+        uint4 v[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) v[k] = *reinterpret_cast<const uint4 *>(src + k * src_step);
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            sk[k] = src + k * src_step;
-            dk[k] = dst + k * dst_step;
-        }
-        asm volatile("" ::: "memory");  // (keeps the address arithmetic out of the divergent regions below)
-        uint4 v[N];
-        if (!is_hdr) {
-#pragma unroll
-            for (int k = 0; k < N; k++) v[k] = *reinterpret_cast<const uint4 *>(sk[k]);
-        }
-        if (is_hdr) {
-#pragma unroll
-            for (int k = 0; k < N; k++) *reinterpret_cast<uint64_t *>(dk[k]) = hdr;
-        } else if (val_hi_compact) {
-            // (w0, w1, w2, sign) -> the Int<4>'s upper two limbs: the sign word four times, as four dword stores of the
-            // ONE register that holds it (a dwordx4 store would want three copies first: VALU work on every wave)
-#pragma unroll
-            for (int k = 0; k < N; k++)
-                asm volatile("global_store_dword %0, %1, off\n\tglobal_store_dword %0, %1, off offset:4\n\t"
-                             "global_store_dword %0, %1, off offset:8\n\tglobal_store_dword %0, %1, off offset:12"
-                             :: "v"(dk[k]), "v"(v[k].w) : "memory");
-        } else {
-#pragma unroll
-            for (int k = 0; k < N; k++) {
-                oc_u128_a8 o;
-                o.x = ((uint64_t)v[k].y << 32) | v[k].x;
-                o.y = ((uint64_t)v[k].w << 32) | v[k].z;
-                *reinterpret_cast<oc_u128_a8 *>(dk[k]) = o;
-            }
+            uint4 o = v[k];
+            if (is_hdr) o = make_uint4(hdr_lo, hdr_hi, v[k].x, v[k].y);
+            if (val_hi_compact) o = make_uint4(v[k].w, v[k].w, v[k].w, v[k].w);
+            oc_u128_a8 w;
+            w.x = ((uint64_t)o.y << 32) | o.x;
+            w.y = ((uint64_t)o.w << 32) | o.z;
+            *reinterpret_cast<oc_u128_a8 *>(dst + k * dst_step) = w;
         }
         src += N * src_step;
         dst += N * dst_step;
