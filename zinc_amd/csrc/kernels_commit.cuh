@@ -1016,12 +1016,33 @@ __global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
 // Digest of a witness (zip_commit's speculative hint, zip_hip.hip): out[0] += sum w[i], out[1] += sum w[i] * (2 i + 1),
 // both mod 2^64.  Not cryptographic: it guards against a caller that overwrote its DEVICE witness between a commit and
 // the transparent re-run of that commit -- any single changed word changes out[0], a permuted array changes out[1].
+// One workgroup per CU, 16 bytes per lane and load, four loads in flight: it runs beside the commit kernel and must
+// not take the co-residency slots of the row combinations and the gathers (2048 workgroups of 8-byte loads took 340 us
+// there and doubled the time of the row combinations).
 __global__ void __launch_bounds__(256) witness_digest_kernel(const uint64_t *w, uint64_t n, unsigned long long *out) {
     unsigned long long a = 0, b = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const unsigned long long v = w[i];
-        a += v;
-        b += v * (2ull * i + 1ull);
+    const uint64_t n2 = n / 2, stride = (uint64_t)gridDim.x * blockDim.x;
+    const ulonglong2 *w2 = reinterpret_cast<const ulonglong2 *>(w);
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n2; i += 4 * stride) {
+        ulonglong2 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = w2[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t j = 2 * (i + k * stride);
+            a += v[k].x + v[k].y;
+            b += v[k].x * (2ull * j + 1ull) + v[k].y * (2ull * j + 3ull);
+        }
+    }
+    for (; i < n2; i += stride) {
+        const ulonglong2 v = w2[i];
+        a += v.x + v.y;
+        b += v.x * (4ull * i + 1ull) + v.y * (4ull * i + 3ull);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        a += w[n - 1];
+        b += w[n - 1] * (2ull * (n - 1) + 1ull);
     }
     for (int off = 32; off > 0; off >>= 1) {
         a += __shfl_down(a, off, 64);

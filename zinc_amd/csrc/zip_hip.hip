@@ -2259,7 +2259,7 @@ int32_t zip_commit_hinted(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zi
 // same buffers (same witness, same tables: the same bits where they already exist), and wait for it.
 static int32_t launch_witness_digest(zip_ctx *ctx, const int64_t *evals_d, size_t n, unsigned long long *out_d, hipStream_t st) {
     HIP_TRY(ctx, hipMemsetAsync(out_d, 0, 16, st));
-    const uint32_t blocks = (uint32_t)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cus * 8);
+    const uint32_t blocks = (uint32_t)std::min<size_t>((n / 2 + 255) / 256, (size_t)ctx->num_cus);
     hipLaunchKernelGGL(witness_digest_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, reinterpret_cast<const uint64_t *>(evals_d),
                        (uint64_t)n, out_d);
     HIP_TRY(ctx, hipGetLastError());
