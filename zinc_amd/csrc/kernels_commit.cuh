@@ -496,6 +496,14 @@ struct ChunkFinisher {
         }
     }
 
+    // behind the row loop: the rest of the last chunk, through the same staged hand-over between the oldest waves.  (Its own
+    // call site, OUTSIDE the loop: inlined a second time inside it, after_hash cost the 16-entry kernel 18 registers.)
+    __device__ __forceinline__ void after_loop(const CommitArgs &a, uint32_t wave, uint32_t lane, uint32_t T) {
+        if (!(HASH && pending)) return;
+        __syncthreads();  // (the head's stores are in L2: what top_of_row + a row's barriers do otherwise)
+        after_hash(a, wave, lane, T);
+    }
+
     // the row of `round` ended chunk cc (every wave calls this)
     __device__ __forceinline__ void chunk_end(const CommitArgs &a, uint32_t first_level, const ChunkCursor &cc, uint32_t round,
                                               bool last, uint32_t tid, uint32_t T) {
@@ -533,10 +541,7 @@ struct ChunkFinisher {
         p_nrows = nrows_c;
         p_lvl = lvl;
         p_index = cc.index;
-        if (last) {  // no next row to hide the rest behind: the same staged hand-over between the oldest waves, at once
-            __syncthreads();  // (the head's stores are in L2: what top_of_row + a row's barriers do otherwise)
-            after_hash(a, wave, lane, T);
-        }
+        // (the last chunk of the kernel has no next row to hide the rest behind: after_loop() pays it at once)
     }
 };
 
@@ -782,6 +787,7 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
         if (tid0 == 0 && a.stamps && round < kStampRec - 8) a.stamps[(size_t)kStampRec * blockIdx.x + 8 + round] = ph_t;
 #endif
     }
+    fin.after_loop(a, wave0, tid0 & 63u, T);
     stamp_clock(a, 1);
 #ifdef ZIPK_DEBUG_STAMPS
     if (tid0 == 0 && a.stamps) {
@@ -1010,6 +1016,7 @@ __global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
             cc.advance(round);
         }
     }
+    fin.after_loop(a, wave0, tid0 & 63u, T);
     stamp_clock(a, 1);
 }
 

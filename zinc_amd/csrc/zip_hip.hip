@@ -2227,9 +2227,9 @@ int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_k
     if (c->hinted && !c->evals && c->evals_ref) {  // a DEVICE witness of the caller's: its digest, beside the commit kernel
         if (pool_alloc(ctx, 16, (void **)&c->digest_d) == ZIP_OK) {
             const size_t n = (size_t)ctx->rows_local * ctx->p.row_len;
-            if (launch_witness_digest(ctx, c->evals_ref, n, c->digest_d, ctx->s_aux) == ZIP_OK) {
+            if (launch_witness_digest(ctx, c->evals_ref, n, c->digest_d, ctx->s_upper) == ZIP_OK) {  // (not s_aux: the fold of the row combinations waits there)
                 c->digest_done = take_dep_event(ctx);
-                (void)hipEventRecord(c->digest_done, ctx->s_aux);
+                (void)hipEventRecord(c->digest_done, ctx->s_upper);
             }
         }
     }
