@@ -2140,7 +2140,9 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
                 c->rank_d = reinterpret_cast<const uint16_t *>(tables_d + kPackedRanksAt);
             }
         }
-        if (with_merkle && nch > 1) {
+        // (a single chunk is published through its counter too: the gather then starts ~5 us after the commit kernel's
+        // last workgroup has published instead of a cross-stream event's ~20 us after the kernel has ended -- 2^20)
+        if (with_merkle && (nch > 1 || (hint_cols && R >= ctx->num_cus))) {
             if (nch <= kRingStride && !ctx->ring_d) {  // first pipelined commit of this ctx
                 if (hipMalloc((void **)&ctx->ring_d, (size_t)kRingSlots * kRingStride * 4) != hipSuccess ||
                     hipMemset(ctx->ring_d, 0, (size_t)kRingSlots * kRingStride * 4) != hipSuccess) {
