@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ZIP_HIP_ABI_VERSION 2
+#define ZIP_HIP_ABI_VERSION 3 /* 3: zip_ctx_set_speculation, zip_open_shard, zip_mctx_roots, zip_mctx_roots_path */
 
 /* status codes */
 #define ZIP_OK 0

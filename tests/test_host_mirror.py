@@ -23,7 +23,7 @@ def test_libraries_load_and_export_every_declared_symbol():
         assert declared == set(symbols), (header, declared ^ set(symbols))
         for s in declared:
             assert hasattr(lib, s), s
-    assert cabi.lib().zip_abi_version() == 2
+    assert cabi.lib().zip_abi_version() == 3
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
