@@ -827,8 +827,10 @@ CommitGeom commit_geom(uint32_t cw, uint32_t row_len) {
     CommitGeom g{};
     if (cw == 16384) { g.e = 16; g.threads = 1024; g.lds = c16_lds_bytes(1024); return g; }
     // cw = 8192, opt-in (ZIP_HIP_WIDE=1): two 512-thread workgroups of the 16-entry kernel per CU instead of one
-    // 1024-thread workgroup of the 8-entry kernel.  Measured: 1.57 ms against 1.53 ms alone at 2^24 -- both sit
-    // at the same share of the VALU issue rate, a second workgroup hides nothing -- and it leaves the gather 10 KB of LDS.
+    // 1024-thread workgroup of the 8-entry kernel.  Measured, round 2: 1.57 ms against 1.53 ms alone at 2^24; round 3
+    // (fixed BLAKE3 order, deferred chunk ends): 1.29 against 1.35 ms ALONE -- the second workgroup does fill the
+    // other's scan passes now -- but 1.99-2.17 against 1.76-1.79 ms per STEP with any chunk schedule and any of the three
+    // gather kernels: it leaves the gathers 7 KB of LDS, and beside them it runs at 1.52-1.98 ms (EXPERIMENTS.md).
     static const bool wide = getenv("ZIP_HIP_WIDE") && atoi(getenv("ZIP_HIP_WIDE")) == 1;
     if (cw == 8192 && row_len == 4096 && wide) { g.e = 16; g.threads = 512; g.lds = c16_lds_bytes(512); return g; }
     if (cw >= 512) { g.e = 8; g.threads = cw / 8; }
