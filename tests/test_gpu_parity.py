@@ -481,6 +481,103 @@ def test_commit_open_in_one_call_is_byte_identical(cabi, geometry, device_out, p
     assert none is None and np.array_equal(proof2, proof_o)
 
 
+@pytest.mark.parametrize("geometry", [(16, None), (20, None), (17, (8192, 16, 16384))])
+@pytest.mark.parametrize("pattern", ["min", "max", "alternating", "runs"])
+def test_commit_extreme_witnesses(cabi, geometry, pattern):
+    """The widest prefix sums the lanes can meet (code_raa.rs:53-72 sizes K for exactly these): every coefficient
+    -2^63, every coefficient 2^63 - 1, alternating signs, long runs of each.  The 16-entry kernel keeps the
+    intermediate codeword as 64 low bits + a one-byte difference of the high word to its thread's prefix
+    (kernels_commit.cuh): these inputs are where that difference is largest.  Rows, every tree layer and the roots
+    equal the oracle's."""
+    nv, geo = geometry
+    z = orc.Zip(nv, geometry=geo) if geo else orc.Zip(nv)
+    n = 1 << nv
+    lo, hi = -(2**63), 2**63 - 1
+    if pattern == "min":
+        evals = np.full(n, lo, dtype=np.int64)
+    elif pattern == "max":
+        evals = np.full(n, hi, dtype=np.int64)
+    elif pattern == "alternating":
+        evals = np.where(np.arange(n) & 1, lo, hi).astype(np.int64)
+    else:
+        evals = np.where((np.arange(n) // 97) & 1, lo, hi).astype(np.int64)
+    rows_o, layers_o, roots_o = z.commit(evals)
+    ctx = _ctx(cabi, z)
+    com, roots = ctx.commit(evals)
+    rows, layers, _ = com.download()
+    com.free()
+    assert np.array_equal(roots, roots_o)
+    assert np.array_equal(rows, rows_o)
+    assert np.array_equal(layers, layers_o[:, : 2 * z.codeword_len - 2])
+
+
+def _expected_openings(z, rows_o, layers_o, cols):
+    """The column-opening section of the proof stream from the oracle's rows and trees (open_z.rs:124-143,
+    pcs/utils.rs:163-176): per opening the column's values, then per row be64(depth) + the siblings, leaf level first."""
+    R, cw, d = z.num_rows, z.codeword_len, z.depth
+    rows3 = np.ascontiguousarray(rows_o.reshape(R, cw, 4).astype("<u8")).view(np.uint8).reshape(R, cw, 32)
+    out = np.zeros((len(cols), R * (32 + 8 + 32 * d)), dtype=np.uint8)
+    hdr = np.frombuffer(int(d).to_bytes(8, "big"), dtype=np.uint8)
+    for i, c in enumerate(int(c) for c in cols):
+        out[i, : R * 32] = rows3[:, c, :].reshape(-1)
+        rec = out[i, R * 32:].reshape(R, 8 + 32 * d)
+        rec[:, :8] = hdr
+        for k in range(d):
+            rec[:, 8 + 32 * k: 40 + 32 * k] = layers_o[:, 2 * cw - ((2 * cw) >> k) + ((c >> k) ^ 1), :]
+    return out.reshape(-1)
+
+
+_COLUMN_LISTS = {
+    "one": lambda cw: [0],
+    "last": lambda cw: [cw - 1],
+    "same-40": lambda cw: [5] * 40,
+    "siblings": lambda cw: [6, 7, 7, 6],
+    "quad": lambda cw: [8, 9, 10, 11, cw - 4, cw - 3, cw - 2, cw - 1],
+    "every-column": lambda cw: list(range(cw)),
+    "descending-even": lambda cw: list(range(cw - 2, -1, -2))[:700],
+    "low-half-twice": lambda cw: (list(range(0, cw // 2, 3)) * 2)[:900],
+    "one-wave": lambda cw: list(range(64, 128)),
+}
+
+
+@pytest.mark.parametrize("geometry", [(16, None), (18, None), (17, (8192, 16, 16384))])
+@pytest.mark.parametrize("which", sorted(_COLUMN_LISTS))
+def test_hinted_and_packed_openings_for_hand_made_column_lists(cabi, geometry, which):
+    """The rank tables of the packed openings and the hint bitmaps under column lists a transcript never squeezes: a
+    single opening, one column forty times, sibling pairs, aligned groups of four (a level-2 node that serves four
+    openings), EVERY column (all bits set: nothing may be skipped), only one wave's columns (every other wave stores
+    nothing), more openings than distinct columns.  Both commit kernels (8 and 16 entries per lane).  The column section
+    equals the oracle's rows and trees byte for byte, the whole proof equals the plain commit + open of the same ctx."""
+    nv, geo = geometry
+    z = orc.Zip(nv, geometry=geo) if geo else orc.Zip(nv)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    evals = _witness(nv, seed=77)
+    rows_o, layers_o, roots_o = z.commit(evals)
+    cols = np.array(_COLUMN_LISTS[which](z.codeword_len), dtype=np.uint32)
+    coeffs = orc.splitmix64(5, z.num_rows).copy()
+    point = orc.point_to_field(f, np.arange(3, nv + 3, dtype=np.int64))
+    lr = z.num_rows.bit_length() - 1
+    q0 = orc.build_eq_x_r(f, point[nv - lr:])
+    ctx = _ctx(cabi, z)
+    ctx.set_speculation(False)
+    plain, roots_p = ctx.commit(evals)
+    ref = plain.open(evals, coeffs, cols, q0, zf)
+    plain.free()
+    assert np.array_equal(roots_p, roots_o)
+    expect = _expected_openings(z, rows_o, layers_o, cols)
+    u_bytes = z.row_len * 64
+    assert np.array_equal(ref[u_bytes: u_bytes + expect.size], expect)
+    proof, roots, _ = ctx.commit_open(evals, coeffs, cols, q0, zf)
+    assert np.array_equal(roots, roots_o)
+    bad = np.flatnonzero(proof != ref)
+    assert bad.size == 0, f"{which}: {bad.size} proof bytes differ, first at {bad[:8]}"
+    com, _ = ctx.commit(evals, hint_cols=cols)
+    again = com.open(evals, coeffs, cols, q0, zf)
+    com.free()
+    assert np.array_equal(again, ref)
+
+
 @pytest.mark.parametrize("num_vars", [12, 18, 22])
 def test_jobs_in_flight_produce_the_same_proofs(cabi, num_vars):
     """zip_commit_open_begin / zip_job_wait: four different polynomials, two jobs in flight at any time (the second
