@@ -139,6 +139,33 @@ def test_open_eval_bit_exact(cabi, num_vars, modulus, fl):
     assert np.array_equal(got, expect)
 
 
+@pytest.mark.parametrize("num_vars", [16, 20, 22])
+@pytest.mark.parametrize("signs", ["same", "opposite", "mixed"])
+def test_row_combinations_at_their_accumulator_bounds(cabi, num_vars, signs):
+    """Every product of the proximity row at its extreme (|coeff * w| = 2^126, zip/utils.rs:94-127 over Int<8>), summed
+    over up to 2048 rows with one sign -- the 192-bit accumulators of combine_rows_kernel and the fold of the partial
+    sums must carry it -- and every q_0 entry at q - 1 beside witnesses of -2^63 / 2^63 - 1 for the evaluation row (no
+    spare bit in the modulus: the carry branch of the reduction, field/config.rs:68-76)."""
+    z = orc.Zip(num_vars)
+    n, R = 1 << num_vars, z.num_rows
+    lo, hi = -(2**63), 2**63 - 1
+    if signs == "same":
+        evals, coeffs = np.full(n, lo, dtype=np.int64), np.full(R, lo, dtype=np.int64)
+    elif signs == "opposite":
+        evals, coeffs = np.full(n, hi, dtype=np.int64), np.full(R, lo, dtype=np.int64)
+    else:
+        evals = np.where(np.arange(n) % 3 == 0, lo, hi).astype(np.int64)
+        coeffs = np.where(np.arange(R) % 5 < 2, lo, hi).astype(np.int64)
+    rc, expect = z.combine_rows_int(coeffs, evals)
+    assert rc == 0
+    ctx = _ctx(cabi, z)
+    assert np.array_equal(ctx.open_testing(evals, coeffs), expect)
+    for modulus in (MOD_NO_SPARE, BENCH_MODULUS):
+        f = orc.make_field(modulus, 4)
+        q0 = orc.field_elems([modulus - 1 - (i % 2) for i in range(R)], 4)
+        assert np.array_equal(ctx.open_eval(evals, q0, cabi.make_field(modulus, 4)), z.combine_rows_field(f, q0, evals))
+
+
 def test_open_eval_single_row_is_map_to_field(cabi):
     z = orc.Zip(0)
     f = orc.make_field(BENCH_MODULUS, 4)
