@@ -157,11 +157,18 @@ __device__ __forceinline__ void reduce_wide(const uint64_t (&y)[FL + 2], const F
 //   over Z :  u'[c]  = sum_r coeff[r] * w[r][c]        192-bit accumulator (|.| < 2^(126+16))
 //   over Fq:  row[c] = sum_r q0_mont[r] * w[r][c] mod q  == the reference's
 //             sum_r q0[r] (x) phi(w[r][c]) because phi(w) = w*R mod q and every
-//             reference operation returns the canonical residue.  w (signed) is
-//             split as (u64)w - 2^64*[w<0]:  A = sum q0*(u64)w,  B = sum_{w<0} q0.
+//             reference operation returns the canonical residue.
+// Both sums run on UNSIGNED operands: with w' = w + 2^63 and c' = c + 2^63 (one xor each)
+//   sum c w  = sum c' w' - 2^63 (sum_r w'[r][c] + sum_r c'[r]) + rows 2^126      (mod 2^192: the value fits)
+//   sum q0 w = sum q0 w' - 2^63 sum_r q0[r]
+// where the sums over r of c' and q0 do not depend on the column: one thread per chunk adds them up (part_k) and the
+// fold applies them.  Every product step is then x * y + r + carry on 32-bit words = one v_mad_u64_u32 (+ the carry
+// add), no sign handling, no masked add of q0 for negative w (round 2's form: 160 VALU instructions per element from
+// 128-bit C arithmetic; this one: ~65).
 // quirk_mod != 0 reproduces the reference's `%=` against a modulus read as a
 // negative Int (see oracle/zip_oracle.c field_from_signed_words): |w| is first
-// reduced modulo quirk_mod = 2^(64*FL) - q when that is < 2^64.
+// reduced modulo quirk_mod = 2^(64*FL) - q when that is < 2^64 (QUIRK: its own instance, the 64-bit division
+// stays out of the common kernel).
 // ---------------------------------------------------------------------------
 struct CombineArgs {
     const int64_t *evals;   // [num_rows][row_len]
@@ -170,83 +177,214 @@ struct CombineArgs {
     uint32_t num_rows, row_len, rows_per_chunk;
     uint32_t prio;  // s_setprio level: the kernel usually runs beside the (older, always ready) hashing waves of the commit
     uint64_t quirk_mod;
-    uint64_t *part_int;  // [chunks][row_len][3]
-    uint64_t *part_a;    // [chunks][row_len][FL+2]
-    uint64_t *part_b;    // [chunks][row_len][FL+1]
+    uint64_t *part_int;  // [chunks][row_len][3]   sum_r c'_r w'_rc - 2^63 sum_r w'_rc   (mod 2^192)
+    uint64_t *part_a;    // [chunks][row_len][FL+2] sum_r q0_r w'_rc
+    uint64_t *part_k;    // [chunks][FL+3]          sum_r q0_r (FL + 1 limbs) | sum_r c'_r (2 limbs)
 };
 
-template <int FL, bool DO_INT, bool DO_FIELD>
+// Accumulators of the row combinations: a value is kept as sum_j (lo[j] + 2^64 top[j]) 2^(32 j), one 96-bit accumulator
+// per 32-bit position.  A 32 x 32 -> 64-bit product goes to its position with ONE v_mad_u64_u32 (64-bit addend, carry
+// out) and one add of the carry: no carry runs between positions inside the row loop, no zero-extended register pairs
+// (the packed form -- x * y + r + carry per word -- cost 25 instructions per 32 x 64-bit product row, half of them moves).
+template <int N>
+struct WideAcc {
+    uint64_t lo[N];
+    uint32_t top[N];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int j = 0; j < N; j++) { lo[j] = 0; top[j] = 0; }
+    }
+    // x * y0 to position J, x * y1 to position J + 1.  Written out: from C (lo += p; top += lo < p) hipcc makes five
+    // instructions per product (multiply, 64-bit add, compare, select, add) where the hardware needs two -- the
+    // multiply-add takes the accumulator as its 64-bit addend and hands the carry out.  gfx950 wants two wait states
+    // between a VALU write of a carry register and the VALU read of it: the second product and one s_nop fill them.
+    template <int J>
+    __device__ __forceinline__ void mad2(uint32_t x, uint32_t y0, uint32_t y1) {
+#ifndef ZIPK_COMBINE_C_ARITH
+        uint64_t carry0;
+        asm("v_mad_u64_u32 %0, %4, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %1, vcc, %5, %7, %1\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32_e64 %2, %4, 0, %2, %4\n\t"
+            "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc"
+            : "+v"(lo[J]), "+v"(lo[J + 1]), "+v"(top[J]), "+v"(top[J + 1]), "=&s"(carry0)
+            : "s"(x), "v"(y0), "v"(y1)
+            : "vcc");
+#else
+        const uint64_t p0 = (uint64_t)x * y0, p1 = (uint64_t)x * y1;
+        const uint64_t s0 = lo[J] + p0, s1 = lo[J + 1] + p1;
+        top[J] += s0 < p0 ? 1u : 0u;
+        top[J + 1] += s1 < p1 ? 1u : 0u;
+        lo[J] = s0;
+        lo[J + 1] = s1;
+#endif
+    }
+    template <int J>
+    __device__ __forceinline__ void add(uint64_t x) {
+        const uint64_t s = lo[J] + x;
+        top[J] += s < x ? 1u : 0u;
+        lo[J] = s;
+    }
+    // the packed value, L 64-bit limbs (the caller knows it fits)
+    template <int L>
+    __device__ __forceinline__ void pack(uint64_t (&out)[L]) const {
+        uint32_t w[2 * L + 3];
+#pragma unroll
+        for (int i = 0; i < 2 * L + 3; i++) w[i] = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const uint32_t part[3] = {(uint32_t)lo[j], (uint32_t)(lo[j] >> 32), top[j]};
+            uint32_t carry = 0;
+#pragma unroll
+            for (int i = j; i < 2 * L; i++) {
+                const uint64_t t = (uint64_t)w[i] + (i - j < 3 ? part[i - j] : 0u) + carry;
+                w[i] = (uint32_t)t;
+                carry = (uint32_t)(t >> 32);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < L; i++) out[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    }
+};
+
+// acc += x[0 .. NX) * (y0 + 2^32 y1), x in 32-bit words: products x[j] y0 at position j, x[j] y1 at position j + 1
+template <int NX, int J = 0, int N>
+__device__ __forceinline__ void mad_words(WideAcc<N> &acc, const uint32_t (&x)[NX], uint32_t y0, uint32_t y1) {
+    if constexpr (J < NX) {
+        acc.template mad2<J>(x[J], y0, y1);
+        mad_words<NX, J + 1>(acc, x, y0, y1);
+    }
+}
+
+#ifndef ZIPK_COMBINE_UNROLL
+#define ZIPK_COMBINE_UNROLL 4
+#endif
+constexpr int kCombineUnroll = ZIPK_COMBINE_UNROLL;
+template <int FL, bool DO_INT, bool DO_FIELD, bool QUIRK>
 __global__ void __launch_bounds__(256) combine_rows_kernel(CombineArgs a) {
     if (a.prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= a.row_len) return;
     const uint32_t chunk = blockIdx.y;
     const uint32_t r0 = chunk * a.rows_per_chunk;
     const uint32_t r1 = min(r0 + a.rows_per_chunk, a.num_rows);
+    // the wave that also adds up the chunk's column-independent sums (wave-uniform)
+    const bool lead = __builtin_amdgcn_readfirstlane((uint32_t)(blockIdx.x == 0 && threadIdx.x < 64)) != 0;
+    constexpr uint64_t kBias = 1ull << 63;
 
-    uint64_t ai[3] = {0, 0, 0};
-    uint64_t A[FL + 2], B[FL + 1];
-#pragma unroll
-    for (int i = 0; i < FL + 2; i++) A[i] = 0;
-#pragma unroll
-    for (int i = 0; i < FL + 1; i++) B[i] = 0;
+    WideAcc<3> P;        // sum c' w'        < rows 2^128
+    WideAcc<1> W;        // sum w'           < rows 2^64
+    WideAcc<2 * FL + 1> A;  // sum q0 w'     < rows 2^(64 FL + 64)
+    P.clear();
+    W.clear();
+    A.clear();
 
-    const int64_t *p = a.evals + (size_t)r0 * a.row_len + col;
-#pragma unroll 4
-    for (uint32_t r = r0; r < r1; r++, p += a.row_len) {
-        int64_t w = *p;
+    const bool live = col < a.row_len;
+    const int64_t *p = a.evals + (size_t)r0 * a.row_len + (live ? col : 0);
+    // (row r's coefficient and q0 entry are the same for every lane: read through the constant address space they
+    // come by scalar loads, issued rows ahead, and are multiplied from SGPRs -- as vector loads each cost a round trip
+    // that the one resident wave of a SIMD had nobody to hide behind; nothing writes them while this kernel runs)
+    const auto *coeffs_k = (const __attribute__((address_space(4))) int64_t *)(uintptr_t)a.coeffs;
+    const auto *q0_k = (const __attribute__((address_space(4))) uint64_t *)(uintptr_t)a.q0;
+    auto one_row = [&](int64_t w, uint32_t r) {
+        const uint64_t wb = (uint64_t)w ^ kBias;
+        uint32_t w0 = (uint32_t)wb, w1 = (uint32_t)(wb >> 32);
         if (DO_INT) {
-            const i128 prod = (i128)a.coeffs[r] * (i128)w;
-            const u128 lo = ((u128)ai[1] << 64 | ai[0]) + (u128)prod;
-            const uint64_t carry = lo < (u128)prod ? 1 : 0;
-            ai[0] = (uint64_t)lo;
-            ai[1] = (uint64_t)(lo >> 64);
-            ai[2] += (uint64_t)(int64_t)(prod >> 127) + carry;  // sign extension word + carry
+            const uint64_t cb = (uint64_t)coeffs_k[r] ^ kBias;  // wave-uniform: scalar load, SGPRs
+            const uint32_t c[2] = {(uint32_t)cb, (uint32_t)(cb >> 32)};
+            mad_words<2>(P, c, w0, w1);
+            W.template add<0>(wb);
         }
         if (DO_FIELD) {
-            if (a.quirk_mod) {
+            if (QUIRK) {  // (the field half only: the combination over the integers sees the entry as it is)
                 const uint64_t mag = (w < 0 ? (uint64_t)0 - (uint64_t)w : (uint64_t)w) % a.quirk_mod;
-                w = (w < 0) ? -(int64_t)mag : (int64_t)mag;
+                const uint64_t qb = (uint64_t)((w < 0) ? -(int64_t)mag : (int64_t)mag) ^ kBias;
+                w0 = (uint32_t)qb;
+                w1 = (uint32_t)(qb >> 32);
             }
-            const uint64_t wu = (uint64_t)w;
-            const uint64_t *q = a.q0 + (size_t)r * FL;  // wave-uniform -> scalar loads
-            uint64_t carry = 0;
+            const auto *q = q0_k + (size_t)r * FL;  // wave-uniform: scalar loads, SGPRs
+            uint32_t qw[2 * FL];
 #pragma unroll
             for (int i = 0; i < FL; i++) {
-                const u128 x = (u128)q[i] * wu + A[i] + carry;
-                A[i] = (uint64_t)x;
-                carry = (uint64_t)(x >> 64);
+                qw[2 * i] = (uint32_t)q[i];
+                qw[2 * i + 1] = (uint32_t)(q[i] >> 32);
             }
-            const u128 y = (u128)A[FL] + carry;
-            A[FL] = (uint64_t)y;
-            A[FL + 1] += (uint64_t)(y >> 64);
-            const uint64_t mask = (w < 0) ? ~(uint64_t)0 : 0;
-            carry = 0;
+            mad_words<2 * FL>(A, qw, w0, w1);
+        }
+    };
+    // (the witness entries of kCombineUnroll rows are requested before the first of them is used: beside the commit
+    // kernel a SIMD holds ONE wave of this kernel, nobody else hides its loads)
+    uint32_t r = r0;
+    for (; r + kCombineUnroll <= r1; r += kCombineUnroll, p += (size_t)kCombineUnroll * a.row_len) {
+        int64_t w[kCombineUnroll];
 #pragma unroll
-            for (int i = 0; i < FL; i++) {
-                const u128 x = (u128)B[i] + (q[i] & mask) + carry;
-                B[i] = (uint64_t)x;
-                carry = (uint64_t)(x >> 64);
-            }
-            B[FL] += carry;
+        for (int k = 0; k < kCombineUnroll; k++) w[k] = p[(size_t)k * a.row_len];
+#pragma unroll
+        for (int k = 0; k < kCombineUnroll; k++) one_row(w[k], r + k);
+    }
+    for (; r < r1; r++, p += a.row_len) one_row(*p, r);
+    if (live) {
+        const size_t slot = (size_t)chunk * a.row_len + col;
+        if (DO_INT) {
+            // P -= W << 63   (192-bit, wraps)
+            uint64_t pl[3], ws[2], wl[3];
+            P.template pack<3>(pl);
+            W.template pack<2>(ws);
+            wl[0] = ws[0] << 63;
+            wl[1] = (ws[0] >> 1) | (ws[1] << 63);
+            wl[2] = ws[1] >> 1;
+            sub_n<3>(pl, wl);
+#pragma unroll
+            for (int i = 0; i < 3; i++) a.part_int[slot * 3 + i] = pl[i];
+        }
+        if (DO_FIELD) {
+            uint64_t al[FL + 2];
+            A.template pack<FL + 2>(al);
+#pragma unroll
+            for (int i = 0; i < FL + 2; i++) a.part_a[slot * (FL + 2) + i] = al[i];
         }
     }
-    const size_t slot = (size_t)chunk * a.row_len + col;
-    if (DO_INT) {
+    if (!lead) return;
+    // the chunk's column-independent sums: the lanes share the rows, then meet through xor shuffles
+    const uint32_t lane = threadIdx.x;
+    uint64_t Q[FL + 1], C[2] = {0, 0};
 #pragma unroll
-        for (int i = 0; i < 3; i++) a.part_int[slot * 3 + i] = ai[i];
+    for (int i = 0; i < FL + 1; i++) Q[i] = 0;
+    for (uint32_t r = r0 + lane; r < r1; r += 64) {
+        if (DO_FIELD) {
+            uint64_t t[FL + 1];
+#pragma unroll
+            for (int i = 0; i < FL; i++) t[i] = a.q0[(size_t)r * FL + i];
+            t[FL] = 0;
+            add_n<FL + 1>(Q, t);
+        }
+        if (DO_INT) {
+            const uint64_t t[2] = {(uint64_t)a.coeffs[r] ^ kBias, 0};
+            add_n<2>(C, t);
+        }
     }
-    if (DO_FIELD) {
 #pragma unroll
-        for (int i = 0; i < FL + 2; i++) a.part_a[slot * (FL + 2) + i] = A[i];
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint64_t t[FL + 1], u[2];
 #pragma unroll
-        for (int i = 0; i < FL + 1; i++) a.part_b[slot * (FL + 1) + i] = B[i];
+        for (int i = 0; i < FL + 1; i++) t[i] = (uint64_t)__shfl_xor((unsigned long long)Q[i], off, 64);
+        u[0] = (uint64_t)__shfl_xor((unsigned long long)C[0], off, 64);
+        u[1] = (uint64_t)__shfl_xor((unsigned long long)C[1], off, 64);
+        add_n<FL + 1>(Q, t);
+        add_n<2>(C, u);
+    }
+    if (lane == 0) {
+        uint64_t *k = a.part_k + (size_t)chunk * (FL + 3);
+#pragma unroll
+        for (int i = 0; i < FL + 1; i++) k[i] = Q[i];
+        k[FL + 1] = C[0];
+        k[FL + 2] = C[1];
     }
 }
 
 struct FinalizeArgs {
-    const uint64_t *part_int, *part_a, *part_b;
+    const uint64_t *part_int, *part_a, *part_k;
     uint32_t chunks, row_len, m_limbs;
+    uint32_t num_rows;    // rows the partial sums cover (the bias terms of combine_rows_kernel scale with it)
     uint32_t prio;        // s_setprio level (see CombineArgs)
     uint64_t *uprime;     // [row_len][m_limbs] little-endian limbs, or null
     uint64_t *row_limbs;  // [row_len][FL] Montgomery little-endian limbs, or null
@@ -256,18 +394,18 @@ struct FinalizeArgs {
 // 16 columns per workgroup, eight threads per column: each sums every eighth chunk (the fold is latency-bound --
 // one thread per column walking all chunks left 16 waves on the whole chip waiting on one load after another),
 // then the eight partial sums meet in LDS and the first thread of the column finishes.
-// 16 columns = 15 KB of LDS: the kernel must fit into the 29 KB the persistent commit workgroups leave free on a
+// 16 columns = 9 KB of LDS: the kernel must fit into the 26 KB the persistent commit workgroups leave free on a
 // CU, or it only starts when they end (32 columns = 30.7 KB waited 1.2 ms for exactly that).
 constexpr uint32_t kFinalizeCols = 16, kFinalizeGroups = 8;
 
 template <int FL, bool DO_INT, bool DO_FIELD>
-// (capped at 88 VGPRs, so that a wave fits into the 96 registers per lane the
+// (capped at 88 VGPRs, so that a wave fits into the registers per lane the
 // hinted commit kernel leaves free on every SIMD; at its natural 126 the kernel waited for the commit to end)
 __global__ void __launch_bounds__(kFinalizeCols * kFinalizeGroups) __attribute__((amdgpu_num_vgpr(88)))
 combine_finalize_kernel(FinalizeArgs a, FieldDev<FL> f) {
     __shared__ uint64_t sh_int[kFinalizeGroups][kFinalizeCols][3];
     __shared__ uint64_t sh_a[kFinalizeGroups][kFinalizeCols][FL + 2];
-    __shared__ uint64_t sh_b[kFinalizeGroups][kFinalizeCols][FL + 2];
+    __shared__ uint64_t sh_k[kFinalizeGroups][FL + 3];
     if (a.prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t lc = threadIdx.x % kFinalizeCols, g = threadIdx.x / kFinalizeCols;
     const uint32_t col = blockIdx.x * kFinalizeCols + lc;
@@ -287,28 +425,60 @@ combine_finalize_kernel(FinalizeArgs a, FieldDev<FL> f) {
         for (int i = 0; i < 3; i++) sh_int[g][lc][i] = s[i];
     }
     if (DO_FIELD) {
-        uint64_t A[FL + 2], Bs[FL + 2];
+        uint64_t A[FL + 2];
 #pragma unroll
-        for (int i = 0; i < FL + 2; i++) { A[i] = 0; Bs[i] = 0; }
+        for (int i = 0; i < FL + 2; i++) A[i] = 0;
         if (valid) {
 #pragma unroll 4
             for (uint32_t c = g; c < a.chunks; c += kFinalizeGroups) {
                 const size_t slot = (size_t)c * a.row_len + col;
-                uint64_t t[FL + 2], u[FL + 2];
+                uint64_t t[FL + 2];
 #pragma unroll
                 for (int i = 0; i < FL + 2; i++) t[i] = a.part_a[slot * (FL + 2) + i];
-                u[0] = 0;  // B * 2^64
-#pragma unroll
-                for (int i = 0; i < FL + 1; i++) u[i + 1] = a.part_b[slot * (FL + 1) + i];
                 add_n<FL + 2>(A, t);
-                add_n<FL + 2>(Bs, u);
             }
         }
 #pragma unroll
-        for (int i = 0; i < FL + 2; i++) { sh_a[g][lc][i] = A[i]; sh_b[g][lc][i] = Bs[i]; }
+        for (int i = 0; i < FL + 2; i++) sh_a[g][lc][i] = A[i];
+    }
+    if (lc == 0) {  // the column-independent sums (part_k), every eighth chunk per group as well
+        uint64_t kq[FL + 1], kc[2] = {0, 0};
+#pragma unroll
+        for (int i = 0; i < FL + 1; i++) kq[i] = 0;
+#pragma unroll 4
+        for (uint32_t c = g; c < a.chunks; c += kFinalizeGroups) {
+            uint64_t q[FL + 1], cs[2];
+#pragma unroll
+            for (int i = 0; i < FL + 1; i++) q[i] = a.part_k[(size_t)c * (FL + 3) + i];
+            cs[0] = a.part_k[(size_t)c * (FL + 3) + FL + 1];
+            cs[1] = a.part_k[(size_t)c * (FL + 3) + FL + 2];
+            add_n<FL + 1>(kq, q);
+            add_n<2>(kc, cs);
+        }
+#pragma unroll
+        for (int i = 0; i < FL + 1; i++) sh_k[g][i] = kq[i];
+        sh_k[g][FL + 1] = kc[0];
+        sh_k[g][FL + 2] = kc[1];
     }
     __syncthreads();
     if (g != 0 || !valid) return;
+    uint64_t K[FL + 3];  // sum_r q0_r (FL + 1 limbs) | sum_r c'_r (2 limbs), all chunks
+    {
+        uint64_t kq[FL + 1], kc[2] = {0, 0};
+#pragma unroll
+        for (int i = 0; i < FL + 1; i++) kq[i] = 0;
+        for (uint32_t k = 0; k < kFinalizeGroups; k++) {
+            uint64_t q[FL + 1], cs[2] = {sh_k[k][FL + 1], sh_k[k][FL + 2]};
+#pragma unroll
+            for (int i = 0; i < FL + 1; i++) q[i] = sh_k[k][i];
+            add_n<FL + 1>(kq, q);
+            add_n<2>(kc, cs);
+        }
+#pragma unroll
+        for (int i = 0; i < FL + 1; i++) K[i] = kq[i];
+        K[FL + 1] = kc[0];
+        K[FL + 2] = kc[1];
+    }
     if (DO_INT) {
         uint64_t s[3] = {0, 0, 0};
         for (uint32_t k = 0; k < kFinalizeGroups; k++) {
@@ -317,6 +487,11 @@ combine_finalize_kernel(FinalizeArgs a, FieldDev<FL> f) {
             for (int i = 0; i < 3; i++) t[i] = sh_int[k][lc][i];
             add_n<3>(s, t);
         }
+        // - 2^63 sum_r c'_r + rows 2^126 (see combine_rows_kernel)
+        uint64_t t[3] = {K[FL + 1] << 63, (K[FL + 1] >> 1) | (K[FL + 2] << 63), K[FL + 2] >> 1};
+        sub_n<3>(s, t);
+        uint64_t u[3] = {0, (uint64_t)(a.num_rows & 3u) << 62, (uint64_t)(a.num_rows >> 2)};
+        add_n<3>(s, u);
         const uint64_t sign = (uint64_t)((int64_t)s[2] >> 63);
         if (a.uprime) {
             for (uint32_t i = 0; i < a.m_limbs; i++)  // write_integer: limbs little-endian, pcs_transcript.rs:115-123
@@ -326,14 +501,18 @@ combine_finalize_kernel(FinalizeArgs a, FieldDev<FL> f) {
     if (DO_FIELD) {
         uint64_t A[FL + 2], Bs[FL + 2];
 #pragma unroll
-        for (int i = 0; i < FL + 2; i++) { A[i] = 0; Bs[i] = 0; }
+        for (int i = 0; i < FL + 2; i++) A[i] = 0;
         for (uint32_t k = 0; k < kFinalizeGroups; k++) {
-            uint64_t t[FL + 2], u[FL + 2];
+            uint64_t t[FL + 2];
 #pragma unroll
-            for (int i = 0; i < FL + 2; i++) { t[i] = sh_a[k][lc][i]; u[i] = sh_b[k][lc][i]; }
+            for (int i = 0; i < FL + 2; i++) t[i] = sh_a[k][lc][i];
             add_n<FL + 2>(A, t);
-            add_n<FL + 2>(Bs, u);
         }
+        // 2^63 sum_r q0_r
+        Bs[0] = K[0] << 63;
+#pragma unroll
+        for (int i = 1; i < FL + 1; i++) Bs[i] = (K[i - 1] >> 1) | (K[i] << 63);
+        Bs[FL + 1] = K[FL] >> 1;
         uint64_t ra[FL], rb[FL];
         reduce_wide<FL>(A, f, ra);
         reduce_wide<FL>(Bs, f, rb);

@@ -1111,26 +1111,33 @@ int32_t run_combine_fl(zip_ctx *ctx, hipStream_t st, const int64_t *evals_d, con
     }
     if (do_field) {
         if (phase != 2 && (rc = pa.get((size_t)chunks * C * (FL + 2) * 8))) return rc;
-        if (phase != 2 && (rc = pb.get((size_t)chunks * C * (FL + 1) * 8))) return rc;
         a.q0 = q0_dv;
         a.part_a = pa.as<uint64_t>();
-        a.part_b = pb.as<uint64_t>();
     }
+    // the column-independent sums of every chunk (combine_rows_kernel: part_k)
+    if (phase != 2 && (rc = pb.get((size_t)chunks * (FL + 3) * 8))) return rc;
+    a.part_k = pb.as<uint64_t>();
     if (phase != 2) {
         LaunchTimer t(ctx, "combine_rows_kernel", st);
         const dim3 grid(bx, chunks), block(256);
-        if (do_int && do_field)
-            hipLaunchKernelGGL((combine_rows_kernel<FL, true, true>), grid, block, 0, st, a);
+        if (a.quirk_mod && do_field) {  // (rare moduli: the instance that carries the 64-bit division)
+            if (do_int)
+                hipLaunchKernelGGL((combine_rows_kernel<FL, true, true, true>), grid, block, 0, st, a);
+            else
+                hipLaunchKernelGGL((combine_rows_kernel<FL, false, true, true>), grid, block, 0, st, a);
+        } else if (do_int && do_field)
+            hipLaunchKernelGGL((combine_rows_kernel<FL, true, true, false>), grid, block, 0, st, a);
         else if (do_int)
-            hipLaunchKernelGGL((combine_rows_kernel<FL, true, false>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((combine_rows_kernel<FL, true, false, false>), grid, block, 0, st, a);
         else
-            hipLaunchKernelGGL((combine_rows_kernel<FL, false, true>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((combine_rows_kernel<FL, false, true, false>), grid, block, 0, st, a);
         HIP_TRY(ctx, hipGetLastError());
     }
     FinalizeArgs fa{};
     fa.part_int = a.part_int;
     fa.part_a = a.part_a;
-    fa.part_b = a.part_b;
+    fa.part_k = a.part_k;
+    fa.num_rows = R;
     fa.chunks = chunks;
     fa.row_len = C;
     fa.m_limbs = ctx->p.m_limbs;
@@ -2637,19 +2644,22 @@ static int32_t open_enqueue(zip_commitment *c, const int64_t *evals_d, const int
     st.n_cols = n_cols;
     st.openings_d = out_d + u_bytes;
     // The two row combinations do not depend on the commitment.  Where to put them (ZIP_HIP_COMBINE):
-    //   split (default) the pass over the witness FIRST on the main stream -- the stream would otherwise idle until the
-    //                   commit kernel publishes its first chunk, and with s_setprio the pass is not starved by the
-    //                   hashing waves (0.26 ms there; 1.5 ms without the priority) -- and the fold of its partial
-    //                   sums LAST, after the gathers: that kernel needs more VGPRs than the commit kernel leaves
-    //                   free, so anywhere earlier it waits for the commit to end (and the gathers behind it);
+    //   first (default) both kernels on the main stream ahead of the gathers -- the stream would otherwise idle until
+    //                   the commit kernel publishes its first chunk, and with s_setprio they are not starved by the
+    //                   hashing waves: 0.07 + 0.02 ms there (round 3's kernels: 64 / 77 VGPRs and 9 KB of LDS, both
+    //                   fit beside the commit workgroups).  1.676 / 1.718 / 1.725 against 1.710 / 1.732 / 1.735 ms
+    //                   per step for `split`, alternated on one box;
+    //   split           the pass over the witness first, the fold of its partial sums LAST on its own stream once the
+    //                   commit kernel has ended (the default while the fold needed 126 VGPRs and could not start
+    //                   before);
     //   tail            both on their own stream, held back until the commit kernel has ended: beside the gather of
-    //                   the last chunk, where the pass takes 0.3 ms and is the end of the step (round 1's default);
+    //                   the last chunk (round 1's default);
     //   last            after the gathers, alone;
-    //   aux             on their own stream from the start;
-    //   first           both on the main stream ahead of the gathers.
+    //   aux             on their own stream from the start.
     static const char *combine_env = getenv("ZIP_HIP_COMBINE");
-    static const int place = !combine_env ? 4 : !strcmp(combine_env, "aux") ? 1 : !strcmp(combine_env, "first") ? 0 :
-                             !strcmp(combine_env, "last") ? 2 : !strcmp(combine_env, "tail") ? 3 : 4;
+    static const int place = !combine_env ? 0 : !strcmp(combine_env, "aux") ? 1 : !strcmp(combine_env, "first") ? 0 :
+                             !strcmp(combine_env, "last") ? 2 : !strcmp(combine_env, "tail") ? 3 :
+                             !strcmp(combine_env, "split") ? 4 : 0;
     const int64_t *coeffs_dv = reinterpret_cast<const int64_t *>(sb + si.off[0]);
     const uint64_t *q0_dv = reinterpret_cast<const uint64_t *>(sb + si.off[1]);
     hipEvent_t staged = take_dep_event(ctx), combined = take_dep_event(ctx);
