@@ -853,7 +853,7 @@ bool commit_supports_hint(uint32_t cw) { return cw >= 512; }
 // one pinned / device block per hinted commit: the bitmaps (<= 5.6 KB for cw <= 16384) at offset 0, the
 // column -> openings tables of zip_commit_open (first[cw] | next[n_cols], u16) at kHintTables
 // (packed openings: the wave table at kHintTables, the ranks of the hinted openings at kPackedRanksAt)
-constexpr uint32_t kRingSlots = 64, kRingStride = 8;  // zip_ctx::ring_d
+constexpr uint32_t kRingSlots = 64, kRingStride = 16;  // zip_ctx::ring_d
 constexpr size_t kHintTables = 8192, kHintBytes = kHintTables + 8 * (8192 / 32) + 4 * 4096 + 64, kPackedRanksAt = kHintTables + 2048;
 // ---- opening hints and packed openings (CommitArgs.need / .pk) -------------------------------------------------
 // Everything a hinted commit derives from its column list, kept per ctx until the list changes (in the prover flow it
@@ -2056,8 +2056,11 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
             // (3,3,3,3,4).  The chain of gathers is what ends a step (each takes about as long as the commit kernel
             // needs for its chunk), so it should start early: against four chunks of four the first gather starts a
             // round earlier; a fifth chunk end costs the commit kernel ~17 us.  1.849 against 1.859-1.872 ms per step.
+            // From 24 rounds (2^26: 32 rounds of the 16-entry kernel, whose chunk-end stage is full with two rows):
+            // chunks of two rounds, at most 16 -- there the gathers have slack (each waits ~0.3 ms for its chunk) and
+            // what ends a step is the last chunk's gather alone: 5.733 / 5.693 against 5.805 / 5.782 ms per step.
             if (sched.empty() && !ctx->n_chunks && rounds >= 12) {
-                const uint32_t n = std::min(8u, rounds / 3), base = rounds / n;
+                const uint32_t n = rounds >= 24 ? std::min(kRingStride, rounds / 2) : std::min(8u, rounds / 3), base = rounds / n;
                 for (uint32_t k = 0; k + 1 < n; k++) sched.push_back(base);
                 sched.push_back(rounds - base * (n - 1));
             }
