@@ -50,8 +50,14 @@ struct CommitArgs {
     // zip_commit_open, packed openings (MODE kStorePacked): what the hinted openings read of the row entries and of
     // tree levels 0..2 is stored DENSELY, per row [values 16 B each | level-0 | level-1 | level-2 nodes 32 B each] in
     // ascending index order, instead of at its sparse natural place (where every 32 bytes read cost a 128-byte line)
-    uint8_t *pk;                // [num_rows][pk_stride]
-    uint32_t pk_stride, pk_off0, pk_off1, pk_off2;  // bytes: row stride, start of the three node sections
+    // Since round 4 both the packed blocks and the tree levels such a commit still stores in `layers` (3 and up) are
+    // ROW-INTERLEAVED in groups of four rows (rows 4q .. 4q+3): member `rank` of a section sits at
+    //   pk + q * 4 * pk_stride + 4 * section_offset + (rank * 4 + (row & 3)) * size        (size 16: values, 32: nodes)
+    // and node slot s (= level_off + index) of row r at byte  ((q * 2cw + s) * 4 + (r & 3)) * 32  of `layers`,
+    // so that what ONE opening reads of four consecutive rows at one level is ONE whole 128-byte line (the gather's
+    // 32-byte reads of lines 512 KB apart were 55.7 M requests per launch at 2^24, profiles/round3_gather_pmc.md).
+    uint8_t *pk;                // [ceil(num_rows / 4)][4 * pk_stride]
+    uint32_t pk_stride, pk_off0, pk_off1, pk_off2;  // bytes: row stride, start of the three node sections (of ONE row)
     const uint32_t *pk_tab;     // [waves][16] words: per wave the 32 16-bit section ranks its lanes' stores start at
     uint32_t *chunk_done;       // [chunks] arrival counters, or null
     // Opening hint (zip_commit_hinted): bitmaps of what an open of the hinted columns will ever read, or null =
@@ -149,6 +155,23 @@ __device__ __forceinline__ void load_hash(const uint32_t *src, uint32_t (&h)[8])
 // hash offset of level k inside one tree of 2*cw slots
 __device__ __forceinline__ uint32_t level_off(uint32_t cw, uint32_t k) { return 2u * cw - ((2u * cw) >> k); }
 
+// Where the tree of `row` starts in `layers` and how many 32-bit words separate consecutive node slots: the natural
+// layout ([row][2cw] hashes), or the row-interleaved one of packed commits (CommitArgs.pk: [row / 4][2cw][row % 4]).
+template <bool ILV>
+__device__ __forceinline__ uint32_t *tree_of(uint32_t *layers, uint32_t cw, uint32_t row) {
+    return ILV ? layers + ((size_t)(row >> 2) * (2u * cw) * 4 + (row & 3u)) * 8 : layers + (size_t)row * (2u * cw) * 8;
+}
+template <bool ILV>
+constexpr uint32_t kNodeWords = ILV ? 32u : 8u;
+
+// Which row of a round a workgroup takes.  Workgroups b and b + 8 share an XCD (round-robin placement: observed, for
+// speed only), so XCD x takes the x-th eighth of the round's rows, in order: the four rows of an interleave group
+// (and the 32 rows of a gather workgroup) are then produced at the same time by workgroups that share an L2, where
+// their quarter-line stores meet before they are written back.  Any bijection of [0, G) is correct.
+__device__ __forceinline__ uint32_t round_slot(uint32_t b, uint32_t G) {
+    return (G & 7u) ? b : (b & 7u) * (G >> 3) + (b >> 3);
+}
+
 // Hash of the complete subtree over the 2^LVL inputs [E0, E0 + 2^LVL) of one thread,
 // written as compile-time recursion so that every hash lives in named registers
 // (a runtime-indexed stack would be placed in scratch memory).  Src provides
@@ -214,9 +237,20 @@ struct StridedLeaves {
     // (row invariant, see store_mask below): bit e = row entry of step e, bit 8 + e = its leaf hash, bits 16.. =
     // the lane's level-1 nodes (E0 / 2), bits 24.. = its level-2 nodes (E0 / 4).
     uint32_t smask = 0xFFFFFFFFu;
-    // MODE 3: this row's packed block, the section offsets and the wave's 32 base ranks (two per word)
-    uint8_t *pk_row = nullptr;
+    // MODE 3: this row's lane of its group's packed block (pk_v: 16-byte values, pk_n: 32-byte nodes; the four rows
+    // of a group are interleaved member by member, CommitArgs.pk), the section offsets (of the group: 4 x a row's) and
+    // the wave's 32 base ranks (two per word)
+    static constexpr uint32_t NW = MODE == kStorePacked ? 32u : 8u;  // words between node slots of `tree` (kNodeWords)
+    uint8_t *pk_v = nullptr, *pk_n = nullptr;
     uint32_t pk_off0 = 0, pk_off1 = 0, pk_off2 = 0;
+    __device__ __forceinline__ void set_packed(const CommitArgs &a, uint32_t row) {
+        uint8_t *g = a.pk + (size_t)(row >> 2) * 4 * a.pk_stride;
+        pk_v = g + (row & 3u) * 16u;
+        pk_n = g + (row & 3u) * 32u;
+        pk_off0 = 4u * a.pk_off0;
+        pk_off1 = 4u * a.pk_off1;
+        pk_off2 = 4u * a.pk_off2;
+    }
     uint32_t ptab[16] = {};
     template <int K>
     __device__ __forceinline__ uint32_t pbase() const { return (ptab[K >> 1] >> ((K & 1) * 16)) & 0xFFFFu; }
@@ -231,7 +265,7 @@ struct StridedLeaves {
         const uint32_t s = (uint32_t)((int32_t)d2 >> 31);
         if (MODE == kStorePacked) {
             const uint32_t pos = pbase<E0>() + lanes_below(__builtin_amdgcn_ballot_w64(true));
-            *reinterpret_cast<uint4 *>(pk_row + (size_t)pos * 16) = make_uint4(d0, d1, d2, s);
+            *reinterpret_cast<uint4 *>(pk_v + (size_t)pos * 64) = make_uint4(d0, d1, d2, s);
         } else if (compact) {
             *reinterpret_cast<uint4 *>(out_row + (size_t)j * 2) = make_uint4(d0, d1, d2, s);
         } else {
@@ -255,7 +289,7 @@ struct StridedLeaves {
         if (!MASKED || (smask & (0x100u << E0))) {
             if (MODE == kStorePacked) {
                 const uint32_t pos = pbase<8 + E0>() + lanes_below(__builtin_amdgcn_ballot_w64(true));
-                store_hash(reinterpret_cast<uint32_t *>(pk_row + pk_off0) + (size_t)pos * 8, h);
+                store_hash(reinterpret_cast<uint32_t *>(pk_n + pk_off0) + (size_t)pos * 32, h);
             } else {
                 store_hash(tree + (size_t)(base + E0 * T + tid) * 8, h);
             }
@@ -272,16 +306,16 @@ struct StridedLeaves {
             const bool odd = tid & 1u;
             const uint32_t pos = (odd ? pbase<16 + (E0 >> 1) * 2 + 1>() : pbase<16 + (E0 >> 1) * 2>()) +
                                  lanes_below(act & (odd ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull));
-            store_hash(reinterpret_cast<uint32_t *>(pk_row + pk_off1) + (size_t)pos * 8, h);
+            store_hash(reinterpret_cast<uint32_t *>(pk_n + pk_off1) + (size_t)pos * 32, h);
         } else if (MODE == kStorePacked && LVL == 2) {  // tid mod 4 = q owns the q-th quarter
             const uint64_t act = __builtin_amdgcn_ballot_w64(true);
             const uint32_t q = tid & 3u;
             constexpr int K0 = 24 + ((E0 >> 2) & 1) * 4;
             const uint32_t b01 = (q & 1u) ? pbase<K0 + 1>() : pbase<K0>(), b23 = (q & 1u) ? pbase<K0 + 3>() : pbase<K0 + 2>();
             const uint32_t pos = ((q & 2u) ? b23 : b01) + lanes_below(act & (0x1111111111111111ull << q));
-            store_hash(reinterpret_cast<uint32_t *>(pk_row + pk_off2) + (size_t)pos * 8, h);
+            store_hash(reinterpret_cast<uint32_t *>(pk_n + pk_off2) + (size_t)pos * 32, h);
         } else {
-            store_hash(tree + ((size_t)level_off(cw, LVL) + n) * 8, h);
+            store_hash(tree + ((size_t)level_off(cw, LVL) + n) * NW, h);
         }
     }
 };
@@ -359,37 +393,40 @@ __device__ __forceinline__ void bfly_hash(Src &src, uint32_t (&h)[8]) {
 // barrier or the LDS counter that the loading wave passes afterwards.
 // Levels [lvl, lvl + nl) (nl = 1 or 2) of the rows of rounds first .. first + nrows_c - 1 of this workgroup from their
 // level lvl - 1 nodes; lane `lane` of `nlanes` takes every nlanes-th group of 2^nl nodes.
+template <bool ILV>
 __device__ __forceinline__ void upper_stage(const CommitArgs &a, uint32_t first, uint32_t nrows_c, uint32_t lvl, uint32_t nl,
                                             uint32_t lane, uint32_t nlanes) {
+    constexpr uint32_t NW = kNodeWords<ILV>;
     const uint32_t cw = a.cw, depth = 31u - __builtin_clz(cw);
     const uint32_t u_shift = depth - (lvl - 1u) - nl;  // log2(groups per row)
     const uint32_t total = nrows_c << u_shift;
+    const uint32_t slot0 = round_slot(blockIdx.x, gridDim.x);
     for (uint32_t idx = lane; idx < total; idx += nlanes) {
         const uint32_t ri = idx >> u_shift, i = idx & ((1u << u_shift) - 1u);
-        const uint32_t r = blockIdx.x + (first + ri) * gridDim.x;
-        uint32_t *tree = a.layers + (size_t)r * (2u * cw) * 8;
-        const uint32_t *ch = tree + ((size_t)level_off(cw, lvl - 1u) + ((size_t)i << nl)) * 8;
+        const uint32_t r = slot0 + (first + ri) * gridDim.x;
+        uint32_t *tree = tree_of<ILV>(a.layers, cw, r);
+        const uint32_t *ch = tree + ((size_t)level_off(cw, lvl - 1u) + ((size_t)i << nl)) * NW;
         uint32_t c0[8], c1[8], h0[8];
         load_hash(ch, c0);
-        load_hash(ch + 8, c1);
+        load_hash(ch + NW, c1);
         if (nl == 1u) {
             blake3_node(c0, c1, h0);
-            store_hash(tree + ((size_t)level_off(cw, lvl) + i) * 8, h0);
+            store_hash(tree + ((size_t)level_off(cw, lvl) + i) * NW, h0);
             if (lvl == depth) store_hash(a.roots + (size_t)r * 8, h0);
         } else {
             uint32_t c2[8], c3[8], h1[8], h2[8];
             blake3_node(c0, c1, h0);
-            uint32_t *o = tree + ((size_t)level_off(cw, lvl) + 2u * i) * 8;
+            uint32_t *o = tree + ((size_t)level_off(cw, lvl) + 2u * i) * NW;
             store_hash(o, h0);
             // (compiler barrier: the second pair is loaded only now -- all four children at once are 16 more live
             // registers at the kernel's tightest point; the latency hides behind the other waves)
             asm volatile("" ::: "memory");
-            load_hash(ch + 16, c2);
-            load_hash(ch + 24, c3);
+            load_hash(ch + 2 * NW, c2);
+            load_hash(ch + 3 * NW, c3);
             blake3_node(c2, c3, h1);
-            store_hash(o + 8, h1);
+            store_hash(o + NW, h1);
             blake3_node(h0, h1, h2);
-            store_hash(tree + ((size_t)level_off(cw, lvl + 1u) + i) * 8, h2);
+            store_hash(tree + ((size_t)level_off(cw, lvl + 1u) + i) * NW, h2);
             if (lvl + 1u == depth) store_hash(a.roots + (size_t)r * 8, h2);
         }
     }
@@ -412,7 +449,7 @@ struct ChunkCursor {
 // LDS words a commit kernel reserves behind its own buffers for ChunkFinisher (one counter per deferred stage)
 constexpr uint32_t kFinisherFlagWords = 16;
 
-template <bool HASH>
+template <bool HASH, bool ILV = false>
 struct ChunkFinisher {
     // what the workgroup still owes of a finished chunk (wave-uniform): the levels from p_lvl up and the publication
     bool pending = false;
@@ -477,13 +514,13 @@ struct ChunkFinisher {
         while (lvl <= depth) {
             const uint32_t nl = depth - lvl >= 1u ? 2u : 1u;
             if (j == 0) {
-                upper_stage(a, p_first, p_nrows, lvl, nl, lane + 64u * wave, 64u * W);
+                upper_stage<ILV>(a, p_first, p_nrows, lvl, nl, lane + 64u * wave, 64u * W);
                 signal(flags, lane);
             } else {
                 owner = (j - 1u) % W;
                 if (wave == owner) {
                     wait_for(flags + (j - 1u), (j == 1u ? W : 1u) * n_deferred);
-                    upper_stage(a, p_first, p_nrows, lvl, nl, lane, 64u);
+                    upper_stage<ILV>(a, p_first, p_nrows, lvl, nl, lane, 64u);
                     signal(flags + j, lane);
                 }
             }
@@ -522,7 +559,7 @@ struct ChunkFinisher {
 #ifndef ZIPK_EXP_NOFINISH  // timing experiment (tools/wg_spread.py): what do the upper levels cost?
         if (lvl <= depth) {  // the head: one stage with every lane at work
             const uint32_t nl = depth - lvl >= 1u ? 2u : 1u;
-            upper_stage(a, first, nrows_c, lvl, nl, tid, T);
+            upper_stage<ILV>(a, first, nrows_c, lvl, nl, tid, T);
             lvl += nl;
         }
 #else
@@ -530,9 +567,9 @@ struct ChunkFinisher {
 #endif
         if (depth == 0 && tid == 0) {  // a one-leaf tree: the root is the leaf hash
             for (uint32_t ri = 0; ri < nrows_c; ri++) {
-                const uint32_t r = blockIdx.x + (first + ri) * gridDim.x;
+                const uint32_t r = round_slot(blockIdx.x, gridDim.x) + (first + ri) * gridDim.x;
                 uint32_t h[8];
-                load_hash(a.layers + (size_t)r * (2u * cw) * 8, h);
+                load_hash(a.layers + (size_t)r * (2u * cw) * 8, h);  // (never interleaved: packed commits have depth >= 3)
                 store_hash(a.roots + (size_t)r * 8, h);
             }
         }
@@ -653,10 +690,10 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
 #endif
     uint32_t round = 0;
     ChunkCursor cc;
-    ChunkFinisher<HASH> fin;
+    ChunkFinisher<HASH, MODE == kStorePacked> fin;
     fin.init(reinterpret_cast<uint32_t *>(rowbuf + row_len), tid0);
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    for (uint32_t row = blockIdx.x; row < a.num_rows; row += gridDim.x, round++) {
+    for (uint32_t row = round_slot(blockIdx.x, gridDim.x); row < a.num_rows; row += gridDim.x, round++) {
 #ifdef ZIPK_DEBUG_STAMPS
         ph_t = wall_clock64();
 #endif
@@ -746,16 +783,13 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
             StridedLeaves<E, MODE, true> src;
             src.out_row = out_row;
             src.compact = a.compact_rows;
-            src.tree = HASH ? a.layers + (size_t)row * (2u * cw) * 8 : nullptr;
+            src.tree = HASH ? tree_of<MODE == kStorePacked>(a.layers, cw, row) : nullptr;
             src.cw = cw;
             src.T = a.nact;
             src.tid = tid;
             src.smask = smask;
             if (MODE == kStorePacked) {
-                src.pk_row = a.pk + (size_t)row * a.pk_stride;
-                src.pk_off0 = a.pk_off0;
-                src.pk_off1 = a.pk_off1;
-                src.pk_off2 = a.pk_off2;
+                src.set_packed(a, row);
 #pragma unroll
                 for (int k = 0; k < 16; k++) src.ptab[k] = ptab[k];
             }
@@ -885,10 +919,10 @@ __global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
 
     uint32_t round = 0;
     ChunkCursor cc;
-    ChunkFinisher<HASH> fin;
+    ChunkFinisher<HASH, MODE == kStorePacked> fin;
     fin.init(reinterpret_cast<uint32_t *>(ghi + T), tid0);
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    for (uint32_t row = blockIdx.x; row < a.num_rows; row += gridDim.x, round++) {
+    for (uint32_t row = round_slot(blockIdx.x, gridDim.x); row < a.num_rows; row += gridDim.x, round++) {
         fin.top_of_row();
         const uint32_t z = opaque_zero(row);
         const uint32_t tid = tid0 + z;
@@ -981,16 +1015,13 @@ __global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
             transpose8(x2, tid);
             StridedLeaves<8, MODE> src;
             if (MODE == kStorePacked) {
-                src.pk_row = a.pk + (size_t)row * a.pk_stride;
-                src.pk_off0 = a.pk_off0;
-                src.pk_off1 = a.pk_off1;
-                src.pk_off2 = a.pk_off2;
+                src.set_packed(a, row);
 #pragma unroll
                 for (int k = 0; k < 16; k++) src.ptab[k] = q ? ptab1[k] : ptab0[k];
             }
             src.out_row = out_row;
             src.compact = a.compact_rows;
-            src.tree = HASH ? a.layers + (size_t)row * (2u * cw) * 8 : nullptr;
+            src.tree = HASH ? tree_of<MODE == kStorePacked>(a.layers, cw, row) : nullptr;
             src.cw = cw;
             src.T = 16;  // entry of step s = 16 s + src.tid (the subtree of lane 8m+s, see above)
             // wave base + 128 (lane / 8) + 8 q + (lane % 8): the low three bits are the lane's, as the butterfly needs

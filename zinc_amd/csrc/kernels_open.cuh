@@ -590,8 +590,9 @@ struct OpenColsArgs {
     uint32_t row_lo, row_hi;  // rows handled by this launch (one pipeline chunk)
     uint32_t rows_per_block;  // even, or the launch has a single block row
     uint32_t prio;            // s_setprio level of the gather waves (tuning knob)
-    // packed openings (CommitArgs.pk): the column values and the siblings of levels 0..2 are read from the row's packed
-    // block at the ranks of pk_rank[opening] = {value, level 0, level 1, level 2} instead of from rows / layers
+    // packed openings (CommitArgs.pk; open_columns_ilv_kernel): the column values and the siblings of levels 0..2 are
+    // read from the packed block of the row's group of four at the ranks of pk_rank[opening] = {value, level 0, level 1,
+    // level 2}, the siblings of levels >= 3 from the row-interleaved `layers` of such a commitment
     const uint8_t *pk;
     uint32_t pk_stride, pk_off0, pk_off1, pk_off2;
     const uint16_t *pk_rank;  // [n_cols][4] (device)
@@ -634,13 +635,7 @@ __global__ void __launch_bounds__(256) open_columns_kernel(OpenColsArgs a) {
         const uint32_t lvl = h >> 1;
         const uint32_t node = cw2 - (cw2 >> lvl) + ((col >> lvl) ^ 1u);
         const uint64_t *src = a.layers + ((size_t)(r0 + rsub) * cw2 + node) * 4 + (h & 1) * 2;
-        size_t src_step = (size_t)RPP * cw2 * 4;
-        if (a.pk && lvl < 3) {
-            const uint32_t off = lvl == 0 ? a.pk_off0 : lvl == 1 ? a.pk_off1 : a.pk_off2;
-            src = reinterpret_cast<const uint64_t *>(a.pk + (size_t)(r0 + rsub) * a.pk_stride + off +
-                                                     (size_t)a.pk_rank[ci * 4 + 1 + lvl] * 32) + (h & 1) * 2;
-            src_step = (size_t)RPP * (a.pk_stride / 8);
-        }
+        const size_t src_step = (size_t)RPP * cw2 * 4;
         unsigned char *dst = img + (size_t)rsub * rec_bytes + 8 + (size_t)h * 16;
         const uint32_t dst_step = RPP * rec_bytes;
         if (h < 2 * d) {
@@ -663,8 +658,7 @@ __global__ void __launch_bounds__(256) open_columns_kernel(OpenColsArgs a) {
             const uint32_t r = r0 + rsub;
             ulonglong2 v;
             if (a.compact_rows) {  // (w0, w1, w2, sign): the upper half of the Int<4> is the sign word four times
-                const uint4 e = a.pk ? *reinterpret_cast<const uint4 *>(a.pk + (size_t)r * a.pk_stride + (size_t)a.pk_rank[ci * 4] * 16)
-                                     : *reinterpret_cast<const uint4 *>(a.rows + ((size_t)r * a.cw + col) * 2);
+                const uint4 e = *reinterpret_cast<const uint4 *>(a.rows + ((size_t)r * a.cw + col) * 2);
                 const uint64_t ss = ((uint64_t)e.w << 32) | e.w;
                 v.x = half ? ss : ((uint64_t)e.y << 32) | e.x;
                 v.y = half ? ss : ((uint64_t)e.w << 32) | e.z;
@@ -728,20 +722,13 @@ __global__ void __launch_bounds__(256) open_columns_stream_kernel(OpenColsArgs a
     const uint8_t *src;
     size_t src_step;
     if (is_val) {
-        if (a.pk) {
-            src = a.pk + (size_t)row * a.pk_stride + (size_t)a.pk_rank[ci * 4] * 16;
-            src_step = (size_t)RPP * a.pk_stride;
-        } else if (a.compact_rows) {
+        if (a.compact_rows) {
             src = reinterpret_cast<const uint8_t *>(a.rows + ((size_t)row * a.cw + col) * 2);
             src_step = (size_t)RPP * a.cw * 16;
         } else {
             src = reinterpret_cast<const uint8_t *>(a.rows + ((size_t)row * a.cw + col) * K + half * 2);
             src_step = (size_t)RPP * a.cw * 8 * K;
         }
-    } else if (a.pk && lvl < 3) {
-        const uint32_t off = lvl == 0 ? a.pk_off0 : lvl == 1 ? a.pk_off1 : a.pk_off2;
-        src = a.pk + (size_t)row * a.pk_stride + off + (size_t)a.pk_rank[ci * 4 + 1 + lvl] * 32 + (is_hdr ? 0u : half * 16u);
-        src_step = (size_t)RPP * a.pk_stride;
     } else {
         const uint32_t node = cw2 - (cw2 >> lvl) + ((col >> lvl) ^ 1u);
         src = reinterpret_cast<const uint8_t *>(a.layers + ((size_t)row * cw2 + node) * 4) + (is_hdr ? 0u : half * 16u);
@@ -802,20 +789,13 @@ __global__ void __launch_bounds__(256) open_columns_lean_kernel(OpenColsArgs a) 
     const uint8_t *src;
     size_t src_step;
     if (is_val) {
-        if (a.pk) {
-            src = a.pk + (size_t)row * a.pk_stride + (size_t)a.pk_rank[ci * 4] * 16;
-            src_step = (size_t)RPP * a.pk_stride;
-        } else if (a.compact_rows) {
+        if (a.compact_rows) {
             src = reinterpret_cast<const uint8_t *>(a.rows + ((size_t)row * a.cw + col) * 2);
             src_step = (size_t)RPP * a.cw * 16;
         } else {
             src = reinterpret_cast<const uint8_t *>(a.rows + ((size_t)row * a.cw + col) * K + half * 2);
             src_step = (size_t)RPP * a.cw * 8 * K;
         }
-    } else if (a.pk && lvl < 3) {
-        const uint32_t off = lvl == 0 ? a.pk_off0 : lvl == 1 ? a.pk_off1 : a.pk_off2;
-        src = a.pk + (size_t)row * a.pk_stride + off + (size_t)a.pk_rank[ci * 4 + 1 + lvl] * 32 + half * 16u;
-        src_step = (size_t)RPP * a.pk_stride;
     } else {
         const uint32_t node = cw2 - (cw2 >> lvl) + ((col >> lvl) ^ 1u);
         src = reinterpret_cast<const uint8_t *>(a.layers + ((size_t)row * cw2 + node) * 4) + half * 16u;
@@ -849,6 +829,126 @@ __global__ void __launch_bounds__(256) open_columns_lean_kernel(OpenColsArgs a) 
     for (; p + 4 <= full; p += 4) passes(std::integral_constant<int, 4>{});
     for (; p < full; p++) passes(std::integral_constant<int, 1>{});
     if (rsub < rest) passes(std::integral_constant<int, 1>{});
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The openings of a PACKED commitment (zip_commit_hinted / zip_commit_open, round 4): everything an opening reads is
+// row-interleaved in groups of four rows (CommitArgs.pk), so the sibling of level k of rows 4q .. 4q+3 is ONE whole
+// 128-byte line -- eight lanes x 16 bytes -- where the natural layout has four 32-byte pieces of four lines 512 KB
+// apart (55.7 M read requests of 33 useful bytes per launch at 2^24, profiles/round3_gather_pmc.md).
+// Workgroup = (opening, block of rows), 256 threads.  Per pass of 32 rows (8 groups):
+//   lane l of a wave:  group l / 8 of the pass, row (l % 8) / 2 of the group, half l % 2 of the 32-byte node
+//   wave w:            levels w, w + 4, w + 8, w + 12 (< depth): one 1 KB wave instruction = 8 whole lines per level
+//   wave 3 also:       the column values (64 lanes = 32 rows x 2 halves of the Int<4>, from the 16-byte entries)
+//   wave 2 also:       the be64(depth) prefix of every record (pcs_transcript.rs:200-203)
+// IMAGE: the byte-exact image of the block's records is assembled in LDS and streamed out as aligned 16-byte stores
+// (a record is only 8-byte aligned in the stream); !IMAGE: every lane stores its 16 bytes where they belong
+// (global_store_dwordx4 at dword alignment; no LDS, no barrier -- for the geometries whose commit kernel leaves no room
+// for an image beside it).
+// Reference: open_merkle_trees_for_column, src/zip/pcs/open_z.rs:124-143; MerkleProof::create_proof,
+// src/zip/pcs/utils.rs:163-176; write_merkle_proof, src/zip/pcs_transcript.rs:198-211.
+template <bool IMAGE>
+__global__ void __launch_bounds__(256) open_columns_ilv_kernel(OpenColsArgs a) {
+    extern __shared__ __align__(16) unsigned char img[];
+    constexpr uint32_t K = 4;  // Int<4> column values (checked by zip_ctx_create)
+    if (a.prio) __builtin_amdgcn_s_setprio(2);  // memory-bound: do not queue behind older hashing waves
+    const uint32_t ci = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    const uint32_t col = a.cols[ci];
+    const uint32_t d = a.depth, cw2 = 2u * a.cw;
+    const uint32_t rec_bytes = 8 + 32 * d;
+    const size_t col_bytes = (size_t)a.num_rows * (8 * K + rec_bytes);
+    uint8_t *base = a.out + (size_t)ci * col_bytes;
+    uint8_t *recs = base + (size_t)a.num_rows * 8 * K;  // record of row r at recs + r * rec_bytes
+    const uint32_t r0 = a.row_lo + blockIdx.y * a.rows_per_block;
+    const uint32_t r1 = min(r0 + a.rows_per_block, a.row_hi);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t sub = lane & 7u, gi = lane >> 3, half = lane & 1u;
+    // wave-uniform per level j (k = wave + 4 j): byte offset of the level's line inside a group, and the group stride
+    const uint8_t *src_base[4];
+    size_t src_gstride[4];
+    uint32_t src_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t k = wave + 4u * j;
+        if (k < 3u) {
+            const uint32_t off = k == 0 ? a.pk_off0 : k == 1 ? a.pk_off1 : a.pk_off2;
+            const uint32_t rank = __builtin_amdgcn_readfirstlane((uint32_t)a.pk_rank[ci * 4 + 1 + k]);
+            src_base[j] = a.pk;
+            src_gstride[j] = (size_t)4 * a.pk_stride;
+            src_off[j] = 4u * off + rank * 128u;
+        } else {
+            const uint32_t node = cw2 - (cw2 >> k) + ((col >> k) ^ 1u);
+            src_base[j] = reinterpret_cast<const uint8_t *>(a.layers);
+            src_gstride[j] = (size_t)cw2 * 128;
+            src_off[j] = 0;
+            // (cw2 * 128 bytes per group: the node's offset can exceed 32 bits at cw = 16384 only by a factor the
+            // size_t product below absorbs)
+            src_base[j] += (size_t)node * 128;
+        }
+    }
+    const uint32_t vrank = __builtin_amdgcn_readfirstlane((uint32_t)a.pk_rank[ci * 4]);
+    const uint64_t hdr = __builtin_bswap64((uint64_t)d);
+    for (uint32_t rb = r0 & ~3u; rb < r1; rb += 32u) {
+        const uint32_t row = rb + 4u * gi + (sub >> 1);
+        const bool ok = row >= r0 && row < r1;
+        const size_t grp = row >> 2;
+        ulonglong2 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (wave + 4u * j < d && ok)
+                v[j] = *reinterpret_cast<const ulonglong2 *>(src_base[j] + grp * src_gstride[j] + src_off[j] + sub * 16u);
+        }
+        // ---- column values: rows[r * cw + col], K limbs little-endian (open_z.rs:130-137), from the 16-byte entry
+        //      (w0, w1, w2, sign): the upper half of the Int<4> is the sign word four times
+        if (wave == 3u) {
+            const uint32_t vrow = rb + (lane >> 1);
+            if (vrow >= r0 && vrow < r1) {
+                const uint4 e = *reinterpret_cast<const uint4 *>(a.pk + (size_t)(vrow >> 2) * 4 * a.pk_stride +
+                                                                 ((size_t)vrank * 4 + (vrow & 3u)) * 16);
+                const uint4 o = half ? make_uint4(e.w, e.w, e.w, e.w) : e;
+                *reinterpret_cast<uint4 *>(base + (size_t)vrow * 8 * K + half * 16) = o;
+            }
+        }
+        if (wave == 2u && lane < 32u) {
+            const uint32_t hrow = rb + lane;
+            if (hrow >= r0 && hrow < r1) {
+                if (IMAGE) *reinterpret_cast<uint64_t *>(img + (size_t)(hrow - r0) * rec_bytes) = hdr;
+                else *reinterpret_cast<uint64_t *>(recs + (size_t)hrow * rec_bytes) = hdr;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t k = wave + 4u * j;
+            if (k < d && ok) {
+                if (IMAGE) {
+                    uint64_t *dst = reinterpret_cast<uint64_t *>(img + (size_t)(row - r0) * rec_bytes + 8 + k * 32u + half * 16u);
+                    dst[0] = v[j].x;
+                    dst[1] = v[j].y;
+                } else {
+                    oc_u128_a8 o;
+                    o.x = v[j].x;
+                    o.y = v[j].y;
+                    *reinterpret_cast<oc_u128_a8 *>(recs + (size_t)row * rec_bytes + 8 + k * 32u + half * 16u) = o;
+                }
+            }
+        }
+    }
+    if (!IMAGE) return;
+    __syncthreads();
+    // ---- stream the image out ----
+    unsigned char *out = recs + (size_t)r0 * rec_bytes;
+    const uint32_t total = (r1 - r0) * rec_bytes;
+    if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        const uint32_t n16 = total / 16;
+        for (uint32_t i = threadIdx.x; i < n16; i += 256)
+            reinterpret_cast<uint4 *>(out)[i] = reinterpret_cast<const uint4 *>(img)[i];
+        if (threadIdx.x == 0 && (total & 15))
+            reinterpret_cast<uint64_t *>(out)[n16 * 2] = reinterpret_cast<const uint64_t *>(img)[n16 * 2];
+    } else {
+        for (uint32_t i = threadIdx.x; i < total / 8; i += 256)
+            reinterpret_cast<uint64_t *>(out)[i] = reinterpret_cast<const uint64_t *>(img)[i];
+    }
 }
 
 }  // namespace zipk

@@ -1234,18 +1234,23 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
     // leaves 11.5 KB per CU and 32 records are 14.6 KB: the gathers then only started when the commit ended).
     static const uint32_t knob_rpb = getenv("ZIP_HIP_GATHER_RPB") ? (uint32_t)atoi(getenv("ZIP_HIP_GATHER_RPB")) : 0u;
     uint32_t rpb = 32u;
+    const size_t rec = 8 + 32 * (size_t)ctx->depth;  // bytes of one record in the LDS image
+    size_t free_lds = 0;
+    {
+        const CommitGeom cg = commit_geom(ctx->p.codeword_len, ctx->p.row_len);
+        const size_t used = (size_t)commit_wgs_per_cu(cg) * cg.lds;
+        free_lds = used < 160u * 1024u ? 160u * 1024u - used : 0;
+    }
     if (knob_rpb >= 2 && knob_rpb <= 128) {
         rpb = knob_rpb & ~1u;  // even; the value copy needs <= 128
     } else {
-        const CommitGeom cg = commit_geom(ctx->p.codeword_len, ctx->p.row_len);
-        size_t used = (size_t)commit_wgs_per_cu(cg) * cg.lds;
-        const size_t rec = 8 + 32 * (size_t)ctx->depth;  // bytes of one record in the LDS image
-        const size_t free_lds = used < 160u * 1024u ? 160u * 1024u - used : 0;
         // (2.5 KB of slack: LDS is handed out in granules -- 24 records = 10.7 KB did NOT get in beside 148.8 KB)
         while (rpb > 8 && rpb * rec + 2560 > free_lds) rpb -= 8;
         // the LAST chunk's gather runs after the commit kernel has ended, with the CU's whole LDS: 96 records per
-        // workgroup move more bytes per workgroup lifetime (0.735 against 0.825 ms for 4096 rows alone at 2^24)
-        if (alone && rpb == 32 && row_hi - row_lo >= 96 && 96 * rec <= 48u * 1024u) rpb = 96;
+        // workgroup move more bytes per workgroup lifetime (0.735 against 0.825 ms for 4096 rows alone at 2^24) -- unless
+        // another job is in flight on the ctx (zip_commit_open_begin: the NEXT job's commit kernel is then resident when
+        // this gather runs, and 40 KB of LDS would wait for that kernel to end)
+        if (alone && rpb == 32 && row_hi - row_lo >= 96 && 96 * rec <= 48u * 1024u && !(ctx->job_busy[0] || ctx->job_busy[1])) rpb = 96;
     }
     a.rows_per_block = (row_hi - row_lo) < rpb ? (row_hi - row_lo) : rpb;
     static const int knob_prio = getenv("ZIP_HIP_GATHER_PRIO") ? atoi(getenv("ZIP_HIP_GATHER_PRIO")) : 1;
@@ -1254,6 +1259,27 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
     // the kernel without an LDS image.  ZIP_HIP_GATHER_STREAM=1 / 0 forces it on / off.
     static const int knob_stream = getenv("ZIP_HIP_GATHER_STREAM") ? atoi(getenv("ZIP_HIP_GATHER_STREAM")) : -1;
     const bool stream = knob_stream >= 0 ? knob_stream == 1 : rpb < 32;
+    if (c->packed) {
+        // a packed commitment: everything row-interleaved in groups of four (open_columns_ilv_kernel); blocks of whole
+        // groups
+        if (stream) {
+            const uint32_t want = (knob_rpb >= 4 && knob_rpb <= 4096) ? (knob_rpb & ~3u) : 32u;
+            a.rows_per_block = want;
+            const dim3 grid(n_cols, (row_hi - row_lo + a.rows_per_block - 1) / a.rows_per_block), block(256);
+            LaunchTimer t(ctx, "open_columns_kernel", st);
+            hipLaunchKernelGGL(open_columns_ilv_kernel<false>, grid, block, 0, st, a);
+            HIP_TRY(ctx, hipGetLastError());
+            return ZIP_OK;
+        }
+        a.rows_per_block = (rpb + 3u) & ~3u;
+        const size_t lds = (size_t)a.rows_per_block * rec;
+        const dim3 grid(n_cols, (row_hi - row_lo + a.rows_per_block - 1) / a.rows_per_block), block(256);
+        if (int32_t rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(open_columns_ilv_kernel<true>), lds)) return rc;
+        LaunchTimer t(ctx, "open_columns_kernel", st);
+        hipLaunchKernelGGL(open_columns_ilv_kernel<true>, grid, block, lds, st, a);
+        HIP_TRY(ctx, hipGetLastError());
+        return ZIP_OK;
+    }
     // ZIP_HIP_GATHER_LEAN=1: the kernel with the fewest VALU instructions (many rows per workgroup, no LDS, no data
     // selects).  Opt-in: beside the commit kernel it is the slower choice -- 1.92-2.01 against 1.80-1.85 ms per step,
     // the commit kernel 1.64-1.72 instead of 1.57 ms: what a gather costs the hashing waves is its VECTOR-MEMORY
@@ -1997,14 +2023,16 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
             size_t alloc = c->rows_bytes;
             if (with_merkle && hint_cols && commit_supports_hint(cw)) {
                 const auto plan = get_hint_plan(ctx, hint_cols, n_hint, c->compact_rows && n_hint && packed_enabled());
-                if (plan->packed) alloc = std::max(alloc, (size_t)R * plan->L.stride);
+                // (packed blocks and the tree levels beside them are interleaved in groups of four rows: CommitArgs.pk)
+                if (plan->packed) alloc = std::max(alloc, (size_t)((R + 3u) & ~3u) * plan->L.stride);
             }
             if ((rc = pool_alloc(ctx, alloc, (void **)&c->rows))) break;
         }
         if (with_merkle) {
             c->layers_bytes = (size_t)R * 2 * cw * 32;
             c->roots_bytes = (size_t)R * 32;
-            if ((rc = pool_alloc(ctx, c->layers_bytes, (void **)&c->layers))) break;
+            // (whole groups of four rows: a packed commit stores its trees row-interleaved)
+            if ((rc = pool_alloc(ctx, (size_t)((R + 3u) & ~3u) * 2 * cw * 32, (void **)&c->layers))) break;
             if ((rc = pool_alloc(ctx, c->roots_bytes, (void **)&c->roots))) break;
         }
         const int64_t *evals_d = evals;
@@ -2467,7 +2495,8 @@ int32_t zip_commitment_upload(zip_ctx *ctx, const uint64_t *rows, const uint8_t 
         if (e == hipSuccess && layers) {
             c->layers_bytes = (size_t)R * 2 * cw * 32;
             c->roots_bytes = (size_t)R * 32;
-            if ((rc = pool_alloc(ctx, c->layers_bytes, (void **)&c->layers))) break;
+            // (whole groups of four rows: a packed commit stores its trees row-interleaved)
+            if ((rc = pool_alloc(ctx, (size_t)((R + 3u) & ~3u) * 2 * cw * 32, (void **)&c->layers))) break;
             if ((rc = pool_alloc(ctx, c->roots_bytes, (void **)&c->roots))) break;
             const size_t w = ((size_t)2 * cw - 2) * 32;
             if (w) e = hipMemcpy2DAsync(c->layers, (size_t)2 * cw * 32, layers, w, w, R, hipMemcpyHostToDevice, ctx->stream);
