@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BENCH_MODULUS = 106319353542452952636349991594949358997917625194731877894581586278529202198383  # benches/zip_benches.rs:253
-PREWARM = 12  # untimed steps of process / device spin-up ahead of the --warmup steps (see main())
+STEADY_AFTER = 12  # a fresh process reaches its steady step time after about this many steps (see main())
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FIELD_LIMBS = 4
 
@@ -247,6 +247,9 @@ def main():
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra leg that runs the same steps as jobs, two in flight (zip_commit_open_begin / "
                          "zip_job_wait); it is reported beside `value`, never as it")
+    ap.add_argument("--steady-only", action="store_true",
+                    help="only the warm-up, cold and steady one-call steps: no event-bracketed second region, no extra legs "
+                         "(the run tools/profile_round.sh traces, so that rocprofv3's per-kernel averages are those of `value`)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="extra leg (1 GPU, reported beside `value`, never as it): this many independent commit+open jobs "
                          "in flight at once, one zip_ctx and one host thread each")
@@ -354,14 +357,23 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
-    # A fresh process reaches its steady step time after ~15 steps (the first five average 5.3 ms: first use of the 2.5 GB
-    # of pooled buffers, table uploads; steps 6-15 1.88 -> 1.78 ms: tools/exp_warmup.py), whatever W the caller asks
-    # for: PREWARM untimed steps come before the W warm-up steps, and the JSON line says so (`prewarm_steps`).
-    for _ in range(PREWARM):
-        step()
+    # `--warmup W` means what it says: W untimed steps, then K timed steps = the COLD figure (`cold` in the JSON line: a
+    # fresh process needs ~15 steps to its steady state -- first use of the 2.5 GB of pooled buffers, table uploads, clocks:
+    # tools/exp_warmup.py).  Those K steps (topped up to STEADY_AFTER if K is smaller) are the spin-up of the steady
+    # measurement that follows; `value` is the steady figure, `untimed_steps_before_value` says how many steps preceded it.
     for _ in range(args.warmup):
         step()
     barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt_cold = time.perf_counter() - t0
+    extra_spinup = max(0, STEADY_AFTER - args.steps)
+    for _ in range(extra_spinup):
+        step()
+    barrier()
+    untimed_before = args.warmup + args.steps + extra_spinup
     # HIP events on the stream the dominant kernel is launched on (its own); the other kernels of a step are timed in a
     # short second region below: events between the kernels of one stream delay every dependent launch by ~12 us
     ctx.set_profiling(0 if os.environ.get("BENCH_NO_EVENTS") else 2)  # (BENCH_NO_EVENTS=1: what do the two events cost?)
@@ -374,19 +386,26 @@ def main():
     if os.environ.get("BENCH_NO_EVENTS"):
         ktimes = {"raa_commit_kernel": (1, float("nan"))}
     clock_mhz = ctx.commit_clock_mhz()  # shader clock during the last timed commit kernel (in-kernel stamps)
-    ctx.set_profiling(True)
     steps_all = min(args.steps, 10)
-    for _ in range(steps_all):
-        step()
-    barrier()
-    ktimes_all = ctx.profile_read()
+    ktimes_all = {}
+    if not args.steady_only:
+        ctx.set_profiling(True)
+        for _ in range(steps_all):
+            step()
+        barrier()
+        ktimes_all = ctx.profile_read()
     ctx.set_profiling(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        t = torch.tensor([dt_cold], dtype=torch.float64, device=xdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_cold = float(t.item())
 
     pipelined = None
+    if args.steady_only:
+        args.no_pipelined = True
     if not args.no_pipelined and world == 1 and not rows_mode and not (args.two_calls or args.no_hint):
         # The same K steps as jobs, two in flight: the next polynomial's commit kernel is queued behind the current
         # one's and runs beside the end of its openings (the last chunk's gather).  Throughput of a prover that has a
@@ -412,10 +431,50 @@ def main():
                      "note": "the same steps queued as jobs, two in flight; `value` above is one proof at a time"}
 
     two_call = None
-    if world == 1 and not rows_mode and not (args.two_calls or args.no_hint):
+    full_mat = None
+    if world == 1 and not rows_mode and not (args.two_calls or args.no_hint) and not args.steady_only:
+        # What MultilinearZip::commit returns in the reference: the WHOLE MultilinearZipData (every encoded row, every tree
+        # node: src/zip/pcs/structs.rs:33-38; benches/zip_benches.rs:118 black-boxes it) -- plain zip_commit with no hint of
+        # any kind (speculation off), then zip_open.  This is what SURVEY 8d's 200 B/coeff prices; reported beside `value`.
+        ctx.set_speculation(False)
+
+        def step_full():
+            com, _ = ctx.commit(evals_d, want_roots=False)
+            com.open(evals_d, coeffs, cols, q0, zf, out=proof)
+            com.free()
+
+        proof_ref = proof.clone()
+        for _ in range(max(args.warmup, 3)):
+            step_full()
+        barrier()
+        ctx.set_profiling(2)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_full()
+        barrier()
+        dtf = time.perf_counter() - t1
+        kf = ctx.profile_read()
+        ctx.set_profiling(False)
+        fl_l, fl_ms = kf.get("raa_commit_kernel", (1, 0.0))
+        full_bytes = per * row_len * 8 + per * cw * 32 * 3
+        full_mat = {"api": "zip_commit (no hint, no speculation: everything MultilinearZipData holds is stored) + zip_open",
+                    "steps": args.steps, "ms_per_step": round(dtf / args.steps * 1e3, 4),
+                    "value": round(n * args.steps / dtf / 1e6, 2), "unit": "MCoeffs/s",
+                    "commit_kernel_avg_launch_ms": round(fl_ms / max(fl_l, 1), 4),
+                    "commit_kernel_hbm_frac": round(full_bytes / (fl_ms / max(fl_l, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if fl_ms else None,
+                    "whole_path_hbm_frac": round(sum(algorithmic_bytes(n, row_len, num_rows, cw, depth, n_cols, fl).values())
+                                                 / (dtf / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                    "proof_identical_to_one_call": bool(torch.equal(proof, proof_ref))}
+        del proof_ref
+
+    if world == 1 and not rows_mode and not (args.two_calls or args.no_hint) and not args.steady_only:
         # The two calls an UNCHANGED ZincProver makes (src/zinc/prover.rs:315-320): plain zip_commit -- no columns in its
         # signature -- then zip_open.  The first opening names the columns; from then on the ctx hints its plain commits
-        # with that list on its own (zip_hip.h: zip_ctx_set_speculation), so this leg should match `value`.
+        # with that list on its own, so this leg should match `value`.  The bench's witness is DEVICE memory, for which
+        # that is opt-in (zip_ctx_set_speculation(ctx, 1): the witness then outlives its handles unchanged); the Rust
+        # binding's HOST witness gets it by default.
+        ctx.set_speculation(True)
+
         def step2():
             com, _ = ctx.commit(evals_d, want_roots=False)
             com.open(evals_d, coeffs, cols, q0, zf, out=proof)
@@ -430,7 +489,8 @@ def main():
             step2()
         barrier()
         dt2c = time.perf_counter() - t1
-        two_call = {"api": "zip_commit + zip_open (no column argument to the commit; speculative hint from the ctx's last opening)",
+        two_call = {"api": "zip_commit + zip_open (no column argument to the commit; speculative hint from the ctx's last opening, "
+                           "zip_ctx_set_speculation(ctx, 1) for a device witness)",
                     "steps": args.steps, "ms_per_step": round(dt2c / args.steps * 1e3, 4),
                     "value": round(n * args.steps / dt2c / 1e6, 2), "unit": "MCoeffs/s",
                     "proof_identical_to_one_call": bool(torch.equal(proof, proof_one_call))}
@@ -504,7 +564,7 @@ def main():
                     "achieved": round(ach_ginst, 1), "peak": round(peak_ginst, 1), "unit": "G wave-inst/s",
                     "frac": round(ach_ginst / peak_ginst, 4)}
         gather_bytes = ab["gather"]
-        g_l, g_ms = ktimes_all.get("open_columns_kernel", (0, 0.0))
+        g_l, g_ms = ktimes_all.get("open_columns_kernel", (0, 0.0))  # (empty under --steady-only)
         g_ms *= args.steps / steps_all  # (the expressions below divide by args.steps)
         configs_idx = {24: "configs[2]", 26: "configs[3] geometry, whole polynomial on one GPU", 20: "configs[1] + open"}.get(nv, "non-headline size")
         out = {
@@ -514,8 +574,11 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "prewarm_steps": PREWARM,  # untimed, before the warm-up steps: a fresh process needs ~15 steps to its steady state
+            "untimed_steps_before_value": untimed_before,  # --warmup, then the K timed COLD steps (`cold`), topped up to 12
             "ms_per_step": round(step_s * 1e3, 4),
+            # the first K steps after only --warmup untimed ones (a fresh process; `value` is the steady state after them)
+            "cold": {"steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_cold / args.steps * 1e3, 4),
+                     "value": round(coeffs_per_step * args.steps / dt_cold / 1e6, 2), "unit": "MCoeffs/s"},
             "higher_is_better": True,
             "scaling": "strong" if rows_mode else "weak",
             "vs_baseline": None,
@@ -564,6 +627,8 @@ def main():
             "kernels_ms_per_step": dict({k: round(v[1] / steps_all, 4) for k, v in sorted(ktimes_all.items())},
                                         **{dom: round(avg_ms * launches / args.steps, 4)}),
         }
+        if full_mat:
+            out["full_materialisation"] = full_mat
         if two_call:
             out["two_call_unchanged_api"] = two_call
         if pipelined:

@@ -134,10 +134,15 @@ void zip_commitment_free(zip_commitment *c);
  * zip_commit calls (with_merkle != 0) with that list on its own -- in the prover's flow (commit, then open on a fresh
  * PcsTranscript: src/zinc/prover.rs:315-320) the columns never change, so the two unchanged calls run at the hinted
  * commit's speed and produce the same bytes.  The handle's semantics stay zip_commit's: whatever it is asked for that
- * the hint did not keep completes it first (a transparent re-run: from the witness zip_open was handed again, from the
- * library's copy of a HOST witness, or from the caller's DEVICE witness -- whose digest, taken beside the commit
- * kernel, must then still match: ZIP_ERR_INVALID_PARAM otherwise).  on = 0 switches the speculation off for the ctx
- * (ZIP_HIP_SPECULATE=0: for the process). */
+ * the hint did not keep completes it first (a transparent re-run of the commit from the witness).
+ *   default      only commits of a HOST witness speculate (the Rust binding's case: poly.evaluations): the re-run reads
+ *                the library's own device copy, nothing changes for the caller's buffers;
+ *   on != 0      commits of a DEVICE witness speculate too.  LIFETIME RULE the caller accepts with this call: the device
+ *                witness of such a commit must stay valid and unchanged until its handle is freed -- a re-run reads it
+ *                again (from the witness zip_open is handed, or from `evals` of the commit, whose digest, taken beside
+ *                the commit kernel, must then still match: ZIP_ERR_INVALID_PARAM otherwise);
+ *   on == 0      no speculation on this ctx.
+ * ZIP_HIP_SPECULATE=0 / 1 makes "off" / "device witnesses too" the process-wide default. */
 int32_t zip_ctx_set_speculation(zip_ctx *ctx, int32_t on);
 
 int32_t zip_commit_hinted(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,

@@ -946,6 +946,48 @@ int orc_commit(const orc_params *p, const uint64_t *evals, uint64_t *rows, uint8
     return err ? ORC_ERR_OVERFLOW : ORC_OK;
 }
 
+/* commit.rs:50-87 row by row, keeping only the roots and the opening blocks of the picked columns
+ * (open_z.rs:124-143, pcs/utils.rs:163-176,220-233, pcs_transcript.rs:115-123,198-211) */
+int orc_commit_open_columns(const orc_params *p, const uint64_t *evals, const uint32_t *cols, uint32_t n_cols,
+                            uint8_t *roots, uint8_t *blocks) {
+    const size_t cw = p->codeword_len, K = p->k_limbs, R = p->num_rows, d = p->depth;
+    const size_t tree_hashes = ((size_t)2 << d) - 1;
+    const size_t rec = 8 + 32 * d, col_bytes = R * (8 * K + rec);
+    int err = 0;
+    for (uint32_t i = 0; i < n_cols; i++)
+        if (cols[i] >= cw) return ORC_ERR_PARAM;
+#pragma omp parallel reduction(| : err)
+    {
+        uint64_t *row_out = (uint64_t *)malloc(cw * K * 8);
+        uint8_t *tl = (uint8_t *)malloc(tree_hashes * 32);
+        if (!row_out || !tl) err |= 2;
+#pragma omp for schedule(dynamic, 1)
+        for (uint32_t r = 0; r < R; r++) {
+            if (!row_out || !tl) continue;
+            if (orc_raa_encode_row(evals + (size_t)r * p->row_len * p->n_limbs, p->n_limbs, p->row_len, p->rep,
+                                   p->perm1, p->perm2, row_out, (uint32_t)K))
+                err |= 1;
+            orc_merkle_tree(p->depth, row_out, (uint32_t)K, tl);
+            if (roots) memcpy(roots + 32 * (size_t)r, tl + 32 * (tree_hashes - 1), 32);
+            for (uint32_t i = 0; i < n_cols; i++) {
+                uint8_t *blk = blocks + (size_t)i * col_bytes;
+                uint8_t *val = blk + (size_t)r * 8 * K; /* write_integer: limbs little-endian, pcs_transcript.rs:115-123 */
+                for (size_t l = 0; l < K; l++) {
+                    const uint64_t w = row_out[(size_t)cols[i] * K + l];
+                    for (int b = 0; b < 8; b++) val[8 * l + b] = (uint8_t)(w >> (8 * b));
+                }
+                uint8_t *rp = blk + R * 8 * K + (size_t)r * rec;
+                for (int k = 0; k < 8; k++) rp[k] = (uint8_t)((uint64_t)d >> (8 * (7 - k)));
+                orc_merkle_path(p->depth, tl, cols[i], rp + 8);
+            }
+        }
+        free(row_out);
+        free(tl);
+    }
+    if (err & 2) return ORC_ERR_ALLOC;
+    return err ? ORC_ERR_OVERFLOW : ORC_OK;
+}
+
 /* zip/utils.rs:94-127 with F = Int<M>; coeffs/evals expanded first (open_z.rs:104-110) */
 int orc_combine_rows_int(const uint64_t *coeffs, uint32_t coeff_limbs, const uint64_t *evals,
                          uint32_t eval_limbs, uint32_t num_rows, uint32_t row_len,

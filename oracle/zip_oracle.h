@@ -158,6 +158,15 @@ int orc_params_init(orc_params *p, uint32_t num_vars, uint32_t n_limbs, uint32_t
 int orc_commit(const orc_params *p, const uint64_t *evals, uint64_t *rows,
                uint8_t *layers, uint8_t *roots);
 
+/* The same commit, kept only as far as a checker of a LARGE instance needs it (2^26: rows + layers would be 12 GiB):
+ * every root (commit.rs:78-81) and, for the n_cols picked columns, the complete opening block that
+ * open_merkle_trees_for_column writes for it (open_z.rs:124-143; pcs/utils.rs:163-176,220-233;
+ * pcs_transcript.rs:198-211): num_rows values (k_limbs LE limbs each), then num_rows x { be64(depth), depth x 32 B }.
+ * Row by row: encode, tree, root, the picked entries and paths; nothing else is retained.
+ * blocks: n_cols * num_rows * (8 k_limbs + 8 + 32 depth) bytes. */
+int orc_commit_open_columns(const orc_params *p, const uint64_t *evals, const uint32_t *cols, uint32_t n_cols,
+                            uint8_t *roots, uint8_t *blocks);
+
 /* combine_rows over Int<M> (zip/utils.rs:94-127 via open_z.rs:103-112). */
 int orc_combine_rows_int(const uint64_t *coeffs, uint32_t coeff_limbs,
                          const uint64_t *evals, uint32_t eval_limbs,

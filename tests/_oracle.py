@@ -426,6 +426,20 @@ class Zip:
         assert rc == 0, rc
         return rows, layers, roots
 
+    def commit_open_columns(self, evals, cols):
+        """Every root and the whole opening block of each picked column, row by row (no rows / layers kept): the
+        checker of the sizes whose full commit does not fit a test (2^26: 12 GiB)."""
+        evals = np.ascontiguousarray(evals, dtype=np.int64)
+        cols = np.ascontiguousarray(cols, dtype=np.uint32)
+        assert evals.size == self.num_rows * self.row_len
+        roots = np.zeros((self.num_rows, 32), dtype=np.uint8)
+        per_col = self.num_rows * (8 * self.k_limbs + 8 + 32 * self.depth)
+        blocks = np.zeros((cols.size, per_col), dtype=np.uint8)
+        rc = lib().orc_commit_open_columns(C.byref(self.p), _u64p(evals.view(np.uint64)), _u32p(cols), int(cols.size),
+                                           _u8p(roots), _u8p(blocks))
+        assert rc == 0, rc
+        return roots, blocks
+
     def proof_len(self, fl):
         return lib().orc_proof_len(C.byref(self.p), fl)
 

@@ -4,7 +4,6 @@ with, and the committed file must be what the generator emits today."""
 import importlib.util
 import json
 import os
-import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -43,13 +42,9 @@ def test_schedule_against_the_golden_blake3_vectors():
     assert done >= 2, "the golden file holds no 32- or 64-byte single-block vectors any more?"
 
 
-def test_committed_include_is_current(tmp_path):
-    """zinc_amd/csrc/blake3_sched.inc == what tools/gen_blake3_sched.py writes (the generator is deterministic)."""
-    path = os.path.join(ROOT, "zinc_amd", "csrc", "blake3_sched.inc")
-    before = open(path).read()
-    try:
-        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_blake3_sched.py")], check=True, capture_output=True)
-        assert open(path).read() == before, "blake3_sched.inc is stale: run tools/gen_blake3_sched.py and rebuild"
-    finally:
-        with open(path, "w") as fh:
-            fh.write(before)
+def test_committed_include_is_current():
+    """zinc_amd/csrc/blake3_sched.inc == what tools/gen_blake3_sched.py renders (the generator is deterministic).  In
+    process: no fork + exec (a GPU-initialised pytest process must not), no write to the tracked file."""
+    g = _gen()
+    with open(g.INC_PATH) as fh:
+        assert fh.read() == g.render(), "blake3_sched.inc is stale: run tools/gen_blake3_sched.py and rebuild"

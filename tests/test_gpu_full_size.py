@@ -1,6 +1,7 @@
-"""BASELINE.json's full sizes on the GPU, checked through size-independent properties and sampled
-rows (the oracle cannot redo 2^24 in test time): sampled encoded rows / trees / roots against the
-oracle, exact proof length, the oracle's verifier accepting the 1.74 GiB proof, linearity."""
+"""BASELINE.json's full sizes on the GPU.  2^24 (configs[2]): every row, tree node, root and proof byte against the
+oracle's whole commit + open (seconds on the box's host cores).  2^26 (configs[3], 12 GiB of rows + trees): all 8192
+roots and 64 whole opening blocks against the oracle's row-by-row pass (orc_commit_open_columns), sampled trees,
+exact proof length, the verifiers on the whole stream, linearity."""
 import os
 
 import numpy as np
@@ -40,66 +41,86 @@ def _check_sampled_rows(z, evals, rows_t, layers_t, roots, sample):
         assert np.array_equal(roots[r], tree[-1]), r
 
 
+def _equal_in_slabs(torch, dev_t, host_a, what, slab=512):
+    """dev_t (device, [rows, ...]) == host_a (numpy, same shape), uploaded in slabs of rows."""
+    for r in range(0, host_a.shape[0], slab):
+        assert torch.equal(dev_t[r:r + slab], torch.from_numpy(host_a[r:r + slab]).cuda()), (what, r)
+
+
 def test_commit_open_2pow24(env):
-    """configs[2]: commit + open at 2^24 (row_len = num_rows = 4096, codeword 8192, depth 13)."""
+    """configs[2]: commit + open at 2^24 (row_len = num_rows = 4096, codeword 8192, depth 13) against the oracle's
+    WHOLE commit and WHOLE proof (a few seconds on the box's host cores): every encoded row, every tree node, all 4096
+    roots and every byte of the 1.74 GiB stream, for the plain two calls, the hinted / packed commit, the one call and
+    the self-hinted plain commit of the unchanged prover flow (commit.rs:78-86, open_z.rs:22-40)."""
     cabi, torch = env
     nv = 24
     z = orc.Zip(nv)
     f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
     evals = orc.splitmix64(0x5A494E43, 1 << nv)
+    point = orc.point_to_field(f, [1] * nv)  # as in the bench (zip_benches.rs:143)
+    rows_o, layers_o, roots_o = z.commit(evals)
+    proof_o, cols, coeffs = z.open(f, evals, rows_o, layers_o, point, orc.new_transcript())  # fresh PcsTranscript
+    lr = z.num_rows.bit_length() - 1
+    q0 = orc.build_eq_x_r(f, point[nv - lr:])
+    assert proof_o.size == z.proof_len(4) == 4096 * 64 + 1000 * 4096 * (32 + 8 + 32 * 13) + 4096 * 32  # commit.rs:712-737
+
     ctx = cabi.ZipContext(nv, z.perm1, z.perm2)
+    ctx.set_speculation(False)  # the first commit below is the plain one: everything materialised
     d_evals = torch.from_numpy(evals).cuda()
     com, roots = ctx.commit(d_evals)
+    assert np.array_equal(roots, roots_o)  # all 4096
     rows_p, layers_p, _ = com.device_ptrs()
     ctx.synchronize()
     rows_t = _dev_view(torch, rows_p, (z.num_rows, z.codeword_len * 4), "<i8")
-    layers_t = _dev_view(torch, layers_p, (z.num_rows, 2 * z.codeword_len * 32), "|u1")
-    _check_sampled_rows(z, evals, rows_t, layers_t, roots, [0, 1, 255, 256, 2047, 4095, 1234, 3333])
+    layers_t = _dev_view(torch, layers_p, (z.num_rows, 2 * z.codeword_len, 32), "|u1")
+    _equal_in_slabs(torch, rows_t, rows_o.view(np.int64).reshape(z.num_rows, z.codeword_len * 4), "rows")
+    nodes = 2 * z.codeword_len - 1  # MerkleTree.layers + the root at slot 2cw - 2 (the device keeps one pad slot more)
+    for r in range(0, z.num_rows, 512):
+        assert torch.equal(layers_t[r:r + 512, :nodes], torch.from_numpy(layers_o[r:r + 512]).cuda()), ("layers", r)
+    del rows_o, layers_o
     # determinism (commit.rs:253-283)
     com2, roots2 = ctx.commit(d_evals)
     assert np.array_equal(roots, roots2)
     com2.free()
 
-    # open with the oracle's Fiat-Shamir stream (fresh PcsTranscript), point = [1; nv] as in the bench
-    point = orc.point_to_field(f, [1] * nv)
-    fs = orc.new_transcript()
-    coeffs = np.zeros(z.num_rows, dtype=np.int64)
-    for r in range(z.num_rows):
-        orc.lib().orc_tr_get_integer_challenge(orc.C.byref(fs), 1, coeffs[r:].ctypes.data_as(orc.C.POINTER(orc.C.c_uint64)))
-    cols = np.array([orc.get_challenge(fs, f) % (1 << 32) % z.codeword_len for _ in range(1000)], dtype=np.uint32)
-    lr = z.num_rows.bit_length() - 1
-    q0 = orc.build_eq_x_r(f, point[nv - lr:])
-    proof = com.open(d_evals, coeffs, cols, q0, cabi.make_field(BENCH_MODULUS, 4))
-    assert proof.size == z.proof_len(4) == 4096 * 64 + 1000 * 4096 * (32 + 8 + 32 * 13) + 4096 * 32  # commit.rs:712-737
-    # byte diff of ten opened-column blocks of the 1.74 GiB stream, at a size where the gather IS pipelined
-    # (four chunks behind the persistent commit kernel): values and whole path records of the sampled rows
-    _diff_proof_columns(z, evals, proof, cols, [0, 1, 2, 250, 499, 500, 777, 997, 998, 999],
-                        [0, 1, 255, 256, 2047, 4095, 1234, 3333], z.row_len * 64)
+    # the plain open of the plain commit: every byte
+    proof = com.open(d_evals, coeffs, cols, q0, zf)
+    assert proof.size == proof_o.size and np.array_equal(proof, proof_o)
+    com.free()
     ev = z.mle_eval(f, evals, point)
     assert z.verify(f, roots, point, ev, proof, check_merkle=True) == 0
     bad = proof.copy()
     bad[proof.size // 2] ^= 1
     assert z.verify(f, roots, point, ev, bad, check_merkle=True) != 0
+    del bad
 
-    # zip_commit_open, packed openings and natural places: the same 1.74 GiB, byte for byte (poisoned buffer first)
-    d_ref = torch.from_numpy(proof).cuda()
-    for packed in ("1", "0"):
-        os.environ["ZIP_HIP_PACKED"] = packed
+    # zip_commit_open (packed + row-interleaved openings, and the natural places), zip_commit_hinted + zip_open, and
+    # the plain zip_commit that hints itself with the columns of the ctx's last opening: the same 1.74 GiB, byte for
+    # byte against the ORACLE's stream (poisoned buffer first)
+    d_ref = torch.from_numpy(proof_o).cuda()
+    for how in ("one_call", "one_call_unpacked", "hinted", "self_hinted"):
+        os.environ["ZIP_HIP_PACKED"] = "0" if how == "one_call_unpacked" else "1"
         try:
             d_one = torch.full((proof.size,), 0x33, dtype=torch.uint8, device="cuda")
             torch.cuda.synchronize()  # the fill runs on torch's stream, the library on its own
-            _, roots_one, _ = ctx.commit_open(d_evals, coeffs, cols, q0, cabi.make_field(BENCH_MODULUS, 4), out=d_one)
+            if how.startswith("one_call"):
+                _, roots_one, _ = ctx.commit_open(d_evals, coeffs, cols, q0, zf, out=d_one)
+            else:
+                ctx.set_speculation(how == "self_hinted")
+                c3, roots_one = ctx.commit(d_evals, hint_cols=cols if how == "hinted" else None)
+                c3.open(d_evals, coeffs, cols, q0, zf, out=d_one)
+                c3.free()
             ctx.synchronize()
         finally:
             os.environ.pop("ZIP_HIP_PACKED", None)
-        assert np.array_equal(roots_one, roots)
-        assert torch.equal(d_one, d_ref), packed
+        assert np.array_equal(roots_one, roots_o), how
+        assert torch.equal(d_one, d_ref), how
         del d_one
     del d_ref
 
     # the device verifier (zip_verify) agrees with the oracle's on the full-size stream, and the witness
     # MLE evaluation (prover.rs:317-319) equals the oracle's
-    zf = cabi.make_field(BENCH_MODULUS, 4)
     q1 = orc.build_eq_x_r(f, point[: nv - lr])
     ev_limbs = np.array(orc.int_to_limbs(ev, 4), dtype=np.uint64)
     d_proof = torch.from_numpy(proof).cuda()
@@ -179,9 +200,10 @@ def _diff_proof_columns(z, evals, proof_t, cols, pick_cols, pick_rows, u_bytes):
 
 def test_commit_open_2pow26_full_on_one_gpu(env):
     """configs[3] at its stated size on ONE device: 2^26 coefficients = 8192 rows x 8192, codeword 16384, depth 14
-    (0.5 GiB witness, 2 GiB of 16-byte row entries, 8 GiB of trees, a 3.7 GiB proof).  Sampled rows / trees / roots
-    against the oracle, determinism, exact proof length (commit.rs:712-737), sampled proof blocks byte for byte,
-    and the device verifier on the whole stream (every byte of it is read there)."""
+    (0.5 GiB witness, 2 GiB of 16-byte row entries, 8 GiB of trees, a 3.7 GiB proof).  ALL 8192 roots and 64 WHOLE
+    opening blocks (8192 values + 8192 path records each) against the oracle's row-by-row pass, sampled trees,
+    determinism, exact proof length (commit.rs:712-737), and the device verifier on the whole stream (every byte of it
+    is read there) -- for the plain and for the hinted (packed, row-interleaved) commit."""
     cabi, torch = env
     nv = 26
     z = orc.Zip(nv)
@@ -193,8 +215,21 @@ def test_commit_open_2pow26_full_on_one_gpu(env):
     ctx = cabi.ZipContext(nv, z.perm1, z.perm2)
     d_evals = torch.from_numpy(evals).cuda()
     sample = [0, 1, 255, 256, 4095, 4096, 8191, 5555]
+    pick = np.unique(np.concatenate([[0, 1, 2, 499, 500, 997, 998, 999], np.arange(7, 1000, 17)]))[:64]
+    assert pick.size == 64
+    roots_o, blocks_o = z.commit_open_columns(evals, cols[pick])  # the oracle: every root, 64 whole opening blocks
+    d_blocks = torch.from_numpy(blocks_o).cuda()
+    per_col = z.num_rows * (32 + 8 + 32 * z.depth)
+
+    def check_blocks(proof_t, what):
+        for k, i in enumerate(pick):
+            o = z.row_len * 64 + int(i) * per_col
+            assert torch.equal(proof_t[o:o + per_col], d_blocks[k]), (what, int(i), int(cols[i]))
+
     # plain commit: everything materialised
+    ctx.set_speculation(False)
     com, roots = ctx.commit(d_evals)
+    assert np.array_equal(roots, roots_o)  # all 8192
     _, layers_p, _ = com.device_ptrs(rows=False)
     ctx.synchronize()
     layers_t = _dev_view(torch, layers_p, (z.num_rows, 2 * z.codeword_len * 32), "|u1")
@@ -209,8 +244,7 @@ def test_commit_open_2pow26_full_on_one_gpu(env):
     assert proof.numel() == z.proof_len(4) == 8192 * 64 + 1000 * 8192 * (32 + 8 + 32 * 14) + 8192 * 32
     com.open(d_evals, coeffs, cols, q0, zf, out=proof)
     ctx.synchronize()
-    u_bytes = z.row_len * 64
-    _diff_proof_columns(z, evals, proof, cols, [0, 1, 499, 998, 999], sample, u_bytes)
+    check_blocks(proof, "plain")
     ev = z.mle_eval(f, evals, point)
     ev_limbs = np.array(orc.int_to_limbs(ev, 4), dtype=np.uint64)
     rep = ctx.verify(roots, proof, coeffs, cols, q0, q1, ev_limbs, zf)
@@ -218,10 +252,12 @@ def test_commit_open_2pow26_full_on_one_gpu(env):
     com.free()
     # the hinted commit (columns known up front): same roots (determinism, commit.rs:253-283), same proof bytes
     com2, roots2 = ctx.commit(d_evals, hint_cols=cols)
-    assert np.array_equal(roots, roots2)
-    proof2 = torch.empty_like(proof)
+    assert np.array_equal(roots_o, roots2)
+    proof2 = torch.full_like(proof, 0x33)
+    torch.cuda.synchronize()
     com2.open(d_evals, coeffs, cols, q0, zf, out=proof2)
     ctx.synchronize()
+    check_blocks(proof2, "hinted")
     assert torch.equal(proof, proof2)
     proof2[proof2.numel() // 2] ^= 1
     rep = ctx.verify(roots, proof2, coeffs, cols, q0, q1, ev_limbs, zf)

@@ -707,6 +707,26 @@ def test_plain_commit_speculates_with_the_last_columns(cabi, num_vars):
     ctx = _ctx(cabi, z)
     d = torch.from_numpy(evals).cuda()
     ctx.set_profiling(True)
+    # 0. the default: a DEVICE witness is never speculated on (the caller was not asked to keep it) ...
+    com, _ = ctx.commit(d)
+    assert np.array_equal(com.open(d, coeffs, cols, q0, zf), proof_o)
+    com.free()
+    ctx.profile_read()
+    com, _ = ctx.commit(d)  # (the ctx has seen the columns by now)
+    rows, _, _ = com.download()
+    assert np.array_equal(rows, rows_o) and ctx.profile_read()["raa_commit_kernel"][0] == 1  # everything was stored
+    com.free()
+    # ... a HOST witness is (the library owns the copy a re-run reads): one launch for commit + open, the same bytes
+    com, roots = ctx.commit(evals)
+    assert np.array_equal(roots, roots_o)
+    assert np.array_equal(com.open(evals, coeffs, cols, q0, zf), proof_o)
+    assert ctx.profile_read()["raa_commit_kernel"][0] == 1
+    rows, _, _ = com.download()  # completes itself from the library's copy: a second launch
+    assert np.array_equal(rows, rows_o) and ctx.profile_read()["raa_commit_kernel"][0] == 1
+    com.free()
+    ctx = _ctx(cabi, z)
+    ctx.set_profiling(True)
+    ctx.set_speculation(True)  # opt in: device witnesses too, from here on
     # 1. nothing seen yet: a full commit; its opening names the columns
     com, roots = ctx.commit(d)
     assert np.array_equal(roots, roots_o)

@@ -147,3 +147,17 @@ def test_single_row_polynomial():
     proof, cols, coeffs = z.open(f, evals, rows, layers, np.zeros((0, 4), dtype=np.uint64), fs)
     assert proof.size == 1000 * (32 + 8 + 32) + 32
     assert int.from_bytes(proof[-32:].tobytes(), "big") == orc.field_from_i64(f, -5)
+
+
+@pytest.mark.parametrize("num_vars", [1, 6, 9, 12])
+def test_streamed_commit_open_columns_equals_commit_then_open(num_vars):
+    """orc_commit_open_columns (the memory-light checker of the 2^26 tests: roots + whole opening blocks, row by row)
+    against orc_commit + orc_open, which restate commit.rs:50-87 and open_z.rs:124-143 and are the pinned ones."""
+    z, f, evals, rows, layers, roots, point, proof, cols, coeffs, ev = _prove(num_vars, BENCH_MODULUS, 4, seed=3)
+    pick = np.array([0, 1, 7, 500, 999, 998], dtype=np.int64)
+    roots2, blocks = z.commit_open_columns(evals, cols[pick])
+    assert np.array_equal(roots2, roots)
+    per_col = z.num_rows * (32 + 8 + 32 * z.depth)
+    u_bytes = z.row_len * 64 if z.num_rows > 1 else 0
+    for k, i in enumerate(pick):
+        assert np.array_equal(blocks[k], proof[u_bytes + i * per_col: u_bytes + (i + 1) * per_col]), (k, i)

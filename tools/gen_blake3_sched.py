@@ -268,13 +268,11 @@ def emit_cpp(name, ops, n_msg):
     return lines
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--check", action="store_true")
-    args = ap.parse_args()
-    check()
-    if args.check:
-        return
+INC_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zinc_amd", "csrc", "blake3_sched.inc")
+
+
+def render():
+    """The text of zinc_amd/csrc/blake3_sched.inc (deterministic)."""
     out = ["// GENERATED by tools/gen_blake3_sched.py -- do not edit (see that file for the why and the how).",
            "// One BLAKE3 compression (cv = IV, counter 0, flags 0x0B) in a fixed, class-alternating instruction order.",
            "#pragma once", "#include <stdint.h>", "", "namespace zipk {", ""]
@@ -286,10 +284,19 @@ def main():
     out.append("// 32-byte message, words 8..15 zero (Int<4> leaf): " + "".join(o['cls'] for o in half)[:96] + "...")
     out += emit_cpp("blake3_sched_half", half, 8)
     out += ["", "}  // namespace zipk", ""]
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zinc_amd", "csrc", "blake3_sched.inc")
-    with open(path, "w") as fh:
-        fh.write("\n".join(out))
-    print("wrote", path)
+    return "\n".join(out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    check()
+    if args.check:
+        return
+    with open(INC_PATH, "w") as fh:
+        fh.write(render())
+    print("wrote", INC_PATH)
 
 
 if __name__ == "__main__":

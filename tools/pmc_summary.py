@@ -80,9 +80,50 @@ def classify(kernel):
         # the natural places, 3 hinted and packed
         mode = {"0": "plain", "1": "hinted", "3": "packed"}.get(args[2] if len(args) > 2 else "0", "plain")
         return "raa_commit_kernel", mode
-    if "open_columns_kernel" in k or "open_columns_stream_kernel" in k:
+    if "open_columns_kernel" in k or "open_columns_stream_kernel" in k or "open_columns_ilv_kernel" in k:
         return "open_columns_kernel", "any"
     return None
+
+
+def steady_stats(trace_dir, bench_log, out_csv):
+    """Per-kernel stats of the STEADY steps only, from the kernel trace itself (rocprofv3's own *_kernel_stats.csv averages
+    every launch of the process, cold warm-up launches included -- round-3 verdict: its average was 8 % off the bench's).
+    The traced `bench.py --steady-only` runs U untimed steps (`untimed_steps_before_value`) and then K timed ones, one
+    commit launch per step: every dispatch that begins before the (U + 1)-th commit kernel is dropped.  Same columns as
+    rocprofv3's table.  False if the trace or the log is not there."""
+    tr = find(trace_dir, "*kernel_trace.csv")
+    if not tr or not bench_log:
+        return False
+    untimed = None
+    try:
+        for line in open(bench_log):
+            if line.startswith("{") and "untimed_steps_before_value" in line:
+                untimed = json.loads(line)["untimed_steps_before_value"]
+    except (OSError, ValueError):
+        return False
+    if untimed is None:
+        return False
+    rows = list(csv.DictReader(open(tr)))
+    commits = sorted(int(r["Start_Timestamp"]) for r in rows if "raa_commit" in r["Kernel_Name"] and ", true" in r["Kernel_Name"].replace(",true", ", true"))
+    if len(commits) <= untimed:
+        return False
+    t0 = commits[untimed]
+    per = collections.defaultdict(list)
+    for r in rows:
+        if int(r["Start_Timestamp"]) >= t0:
+            per[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    total = sum(sum(v) for v in per.values()) or 1
+    with open(out_csv, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            m = sum(v) / len(v)
+            sd = (sum((x - m) ** 2 for x in v) / len(v)) ** 0.5
+            w.writerow([k, len(v), sum(v), f"{m:.6f}", f"{100.0 * sum(v) / total:.2f}", min(v), max(v), f"{sd:.6f}"])
+    with open(out_csv + ".note", "w") as fh:
+        fh.write(f"steady-state launches only: every dispatch before the {untimed + 1}-th commit kernel of the traced "
+                 f"`bench.py --steady-only` run dropped (tools/pmc_summary.py steady_stats)\n")
+    return True
 
 
 def main():
@@ -90,6 +131,7 @@ def main():
     ap.add_argument("--trace"), ap.add_argument("--fetch"), ap.add_argument("--write")
     ap.add_argument("--sq"), ap.add_argument("--verify"), ap.add_argument("--sumcheck"), ap.add_argument("--prover")
     ap.add_argument("--cal")
+    ap.add_argument("--bench-log", help="the traced bench.py's output: its JSON line says how many steps preceded the timed ones")
     ap.add_argument("--tag", default="round2")
     ap.add_argument("--name-suffix", default="")
     ap.add_argument("--num-vars", type=int, default=24)
@@ -98,9 +140,10 @@ def main():
     os.makedirs(prof, exist_ok=True)
     tag = a.tag + a.name_suffix
     if a.trace:
-        st = find(a.trace, "*kernel_stats.csv")
-        if st:
-            shutil.copy(st, os.path.join(prof, f"{tag}_kernel_stats.csv"))
+        if not steady_stats(a.trace, a.bench_log, os.path.join(prof, f"{tag}_kernel_stats.csv")):
+            st = find(a.trace, "*kernel_stats.csv")
+            if st:
+                shutil.copy(st, os.path.join(prof, f"{tag}_kernel_stats.csv"))
     for d, name in ((a.verify, "verify"), (a.sumcheck, "sumcheck"), (a.prover, "prover")):
         st = find(d, "*kernel_stats.csv") if d else None
         if st:
@@ -135,11 +178,11 @@ def main():
         lines = [f"# {tag}: per-launch counters from rocprofv3 --pmc (separate passes), num_vars = {a.num_vars}", "",
                  "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; how to read FETCH_SIZE for each access pattern",
                  f"is measured in `{a.tag}_fetch_calibration.md`.  SQ_INSTS_VALU = VALU wave-instructions issued;",
-                 "SQ_ACTIVE_INST_VALU = quad-cycles a VALU instruction was executing, SQ_WAVE_CYCLES = quad-cycles of wave",
-                 "residency (both summed over waves); `VALU busy while resident` = ACTIVE_INST_VALU / (WAVE_CYCLES / waves per SIMD)",
-                 "for the commit kernel's 4 waves per SIMD.  Kernel sources measured: " + (f"`{sha}`" if sha else "(not recorded)") + ".", "",
-                 "| kernel | launches | FETCH_SIZE KiB | WRITE_SIZE KiB | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU | SQ_WAVE_CYCLES | VALU busy while resident (4 waves/SIMD) |",
-                 "|---|---|---|---|---|---|---|---|"]
+                 "SQ_ACTIVE_INST_VALU = quad-cycles a VALU instruction was executing.  (SQ_WAVE_CYCLES is collected but NOT",
+                 "tabulated as residency: on this chip it does not measure it -- profiles/round3_wg_spread.md -- and the",
+                 "ratio round 3 printed from it exceeded 1.)  Kernel sources measured: " + (f"`{sha}`" if sha else "(not recorded)") + ".", "",
+                 "| kernel | launches | FETCH_SIZE KiB | WRITE_SIZE KiB | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU |",
+                 "|---|---|---|---|---|---|"]
         path = os.path.join(prof, "pmc_traffic.json")
         try:
             traffic = json.load(open(path))
@@ -149,8 +192,7 @@ def main():
             fk, wk, ik = avg(fetch.get(k, [])), avg(write.get(k, [])), avg(insts.get(k, []))
             n = max(len(fetch.get(k, [])), len(write.get(k, [])), len(insts.get(k, [])))
             ak, ck = avg(active.get(k, [])), avg(wcyc.get(k, []))
-            busy = f"{ak / (ck / 4):.3f}" if (ck and "raa_commit" in k) else ""
-            lines.append(f"| `{k[:80]}` | {n} | {fk:,.0f} | {wk:,.0f} | {ik:,.0f} | {ak:,.0f} | {ck:,.0f} | {busy} |")
+            lines.append(f"| `{k[:80]}` | {n} | {fk:,.0f} | {wk:,.0f} | {ik:,.0f} | {ak:,.0f} |")
             cl = classify(k)
             if cl:
                 traffic[f"{cl[0]}:{a.num_vars}:{cl[1]}"] = {

@@ -3,24 +3,26 @@
 # 2^26, 2^20), the PMC passes (FETCH_SIZE, WRITE_SIZE separately: they do not fit one pass; SQ_INSTS_VALU,
 # SQ_ACTIVE_INST_VALU, SQ_WAVE_CYCLES) of hinted and plain commit + open at 2^24 and 2^26, the FETCH_SIZE calibration,
 # the per-workgroup stamps of the commit kernel, the issue-rate micro-benchmarks; condensed into profiles/<tag>_*.
-#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh round3 > gpurun_out/prof.log 2>&1; tail -40 gpurun_out/prof.log'
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh round4 > gpurun_out/prof.log 2>&1; tail -40 gpurun_out/prof.log'
 # "full" as second argument also re-traces the verifier, the sumcheck prover and the whole ZincProver.
 # (every step appends to gpurun_out/prof_progress.log: a run that writes nothing for 7 minutes is taken to be hung)
 set -e
-TAG="${1:-round3}"
+TAG="${1:-round4}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/round_prof; rm -rf $OUT; mkdir -p $OUT
 P=gpurun_out/prof_progress.log; : > $P
 say() { echo "$(date +%T) $*" >> $P; }
 make -C oracle > /dev/null 2>&1 || true
-say trace24; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
-say trace24-nohint; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_nohint -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-hint > $OUT/bench_trace_nohint.log 2>&1
-say trace26; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace26 -- python3 bench.py --num-vars 26 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_trace26.log 2>&1
-say trace20; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace20 -- python3 bench.py --num-vars 20 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_trace20.log 2>&1
-python3 tools/pmc_summary.py --tag "$TAG" --trace $OUT/trace
-python3 tools/pmc_summary.py --tag "$TAG" --name-suffix _nohint --trace $OUT/trace_nohint
-python3 tools/pmc_summary.py --tag "$TAG" --name-suffix _2pow26 --trace $OUT/trace26
-python3 tools/pmc_summary.py --tag "$TAG" --name-suffix _2pow20 --trace $OUT/trace20
+# (--steady-only: warm-up, cold and steady one-call steps, nothing else; the summaries keep the steady launches only, so
+# that AverageNs of the dominant kernel is the `avg_launch_ms` of the traced run's JSON line)
+say trace24; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --steady-only > $OUT/bench_trace.log 2>&1
+say trace24-nohint; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_nohint -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --steady-only --no-hint > $OUT/bench_trace_nohint.log 2>&1
+say trace26; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace26 -- python3 bench.py --num-vars 26 --steps 8 --warmup 2 --no-cpu-baseline --steady-only > $OUT/bench_trace26.log 2>&1
+say trace20; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace20 -- python3 bench.py --num-vars 20 --steps 20 --warmup 5 --no-cpu-baseline --steady-only > $OUT/bench_trace20.log 2>&1
+python3 tools/pmc_summary.py --tag "$TAG" --trace $OUT/trace --bench-log $OUT/bench_trace.log
+python3 tools/pmc_summary.py --tag "$TAG" --name-suffix _nohint --trace $OUT/trace_nohint --bench-log $OUT/bench_trace_nohint.log
+python3 tools/pmc_summary.py --tag "$TAG" --name-suffix _2pow26 --trace $OUT/trace26 --bench-log $OUT/bench_trace26.log
+python3 tools/pmc_summary.py --tag "$TAG" --name-suffix _2pow20 --trace $OUT/trace20 --bench-log $OUT/bench_trace20.log
 python3 tools/timeline.py $OUT/trace -5 > $OUT/timeline24.txt 2>&1 || true
 python3 tools/timeline.py $OUT/trace20 -5 > $OUT/timeline20.txt 2>&1 || true
 # counter collection serialises kernel dispatch (no commit/open pipelining in these passes): one chunk

@@ -43,7 +43,7 @@ def hipcc():
 def build_hip(force=False, verbose=False, extra=()):
     os.makedirs(LIB, exist_ok=True)
     target = os.path.join(LIB, "libzip_hip.so")
-    deps = _sources(CSRC, (".hip", ".cuh", ".h")) + _sources(INCLUDE, (".h",))
+    deps = _sources(CSRC, (".hip", ".cuh", ".h", ".inc")) + _sources(INCLUDE, (".h",))
     if force or _newer(target, deps):
         cmd = [hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-shared", "-fPIC",
                "-Wall", "-Wno-unused-function", *extra, "-o", target, os.path.join(CSRC, "zip_hip.hip")]

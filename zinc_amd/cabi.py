@@ -491,7 +491,9 @@ class ZipContext:
         self._check(lib().zip_ctx_set_profiling(self._h, int(on)), "zip_ctx_set_profiling")
 
     def set_speculation(self, on=True):
-        """zip_ctx_set_speculation: plain commits hint themselves with the columns of the ctx's last opening (default on)."""
+        """zip_ctx_set_speculation: plain commits hint themselves with the columns of the ctx's last opening.  Default: only
+        commits of a HOST witness do; on=True extends it to DEVICE witnesses (which must then outlive their handles
+        unchanged), on=False switches it off."""
         self._check(lib().zip_ctx_set_speculation(self._h, int(on)), "zip_ctx_set_speculation")
 
     def profile_read(self):

@@ -596,6 +596,10 @@ struct OpenColsArgs {
     const uint8_t *pk;
     uint32_t pk_stride, pk_off0, pk_off1, pk_off2;
     const uint16_t *pk_rank;  // [n_cols][4] (device)
+    // open_columns_ilv_kernel: everything workgroup x needs to know in ONE 16-byte entry (or null: order / cols / pk_rank)
+    //   .x = opening | column << 16      .y = rank of the value | of the level-0 sibling << 16
+    //   .z = rank of the level-1 sibling | of the level-2 sibling << 16
+    const uint4 *wg_tab;
 };
 
 // Grid (n_cols, row blocks): blocks that run together share a narrow band of rows, so the
@@ -848,13 +852,30 @@ __global__ void __launch_bounds__(256) open_columns_lean_kernel(OpenColsArgs a) 
 // for an image beside it).
 // Reference: open_merkle_trees_for_column, src/zip/pcs/open_z.rs:124-143; MerkleProof::create_proof,
 // src/zip/pcs/utils.rs:163-176; write_merkle_proof, src/zip/pcs_transcript.rs:198-211.
+typedef uint32_t oc_u32x4 __attribute__((ext_vector_type(4)));
+
 template <bool IMAGE>
 __global__ void __launch_bounds__(256) open_columns_ilv_kernel(OpenColsArgs a) {
     extern __shared__ __align__(16) unsigned char img[];
     constexpr uint32_t K = 4;  // Int<4> column values (checked by zip_ctx_create)
     if (a.prio) __builtin_amdgcn_s_setprio(2);  // memory-bound: do not queue behind older hashing waves
-    const uint32_t ci = a.order ? a.order[blockIdx.x] : blockIdx.x;
-    const uint32_t col = a.cols[ci];
+    uint32_t ci, col, rk[4];
+    if (a.wg_tab) {  // (one scalar 16-byte load instead of a chain of two dependent table reads)
+        const uint4 t = a.wg_tab[blockIdx.x];
+        ci = t.x & 0xFFFFu;
+        col = t.x >> 16;
+        rk[0] = t.y & 0xFFFFu;
+        rk[1] = t.y >> 16;
+        rk[2] = t.z & 0xFFFFu;
+        rk[3] = t.z >> 16;
+    } else {
+        ci = a.order ? a.order[blockIdx.x] : blockIdx.x;
+        col = a.cols[ci];
+#pragma unroll
+        for (int k = 0; k < 4; k++) rk[k] = a.pk_rank[ci * 4 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) rk[k] = __builtin_amdgcn_readfirstlane(rk[k]);
     const uint32_t d = a.depth, cw2 = 2u * a.cw;
     const uint32_t rec_bytes = 8 + 32 * d;
     const size_t col_bytes = (size_t)a.num_rows * (8 * K + rec_bytes);
@@ -873,7 +894,7 @@ __global__ void __launch_bounds__(256) open_columns_ilv_kernel(OpenColsArgs a) {
         const uint32_t k = wave + 4u * j;
         if (k < 3u) {
             const uint32_t off = k == 0 ? a.pk_off0 : k == 1 ? a.pk_off1 : a.pk_off2;
-            const uint32_t rank = __builtin_amdgcn_readfirstlane((uint32_t)a.pk_rank[ci * 4 + 1 + k]);
+            const uint32_t rank = k == 0 ? rk[1] : k == 1 ? rk[2] : rk[3];
             src_base[j] = a.pk;
             src_gstride[j] = (size_t)4 * a.pk_stride;
             src_off[j] = 4u * off + rank * 128u;
@@ -887,26 +908,26 @@ __global__ void __launch_bounds__(256) open_columns_ilv_kernel(OpenColsArgs a) {
             src_base[j] += (size_t)node * 128;
         }
     }
-    const uint32_t vrank = __builtin_amdgcn_readfirstlane((uint32_t)a.pk_rank[ci * 4]);
+    const uint32_t vrank = rk[0];
     const uint64_t hdr = __builtin_bswap64((uint64_t)d);
     for (uint32_t rb = r0 & ~3u; rb < r1; rb += 32u) {
         const uint32_t row = rb + 4u * gi + (sub >> 1);
         const bool ok = row >= r0 && row < r1;
         const size_t grp = row >> 2;
-        ulonglong2 v[4];
+        oc_u32x4 v[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (wave + 4u * j < d && ok)
-                v[j] = *reinterpret_cast<const ulonglong2 *>(src_base[j] + grp * src_gstride[j] + src_off[j] + sub * 16u);
+                v[j] = *reinterpret_cast<const oc_u32x4 *>(src_base[j] + grp * src_gstride[j] + src_off[j] + sub * 16u);
         }
         // ---- column values: rows[r * cw + col], K limbs little-endian (open_z.rs:130-137), from the 16-byte entry
         //      (w0, w1, w2, sign): the upper half of the Int<4> is the sign word four times
         if (wave == 3u) {
             const uint32_t vrow = rb + (lane >> 1);
             if (vrow >= r0 && vrow < r1) {
-                const uint4 e = *reinterpret_cast<const uint4 *>(a.pk + (size_t)(vrow >> 2) * 4 * a.pk_stride +
-                                                                 ((size_t)vrank * 4 + (vrow & 3u)) * 16);
-                const uint4 o = half ? make_uint4(e.w, e.w, e.w, e.w) : e;
+                const oc_u32x4 e = *reinterpret_cast<const oc_u32x4 *>(a.pk + (size_t)(vrow >> 2) * 4 * a.pk_stride +
+                                                                       ((size_t)vrank * 4 + (vrow & 3u)) * 16);
+                const uint4 o = half ? make_uint4(e.w, e.w, e.w, e.w) : make_uint4(e.x, e.y, e.z, e.w);
                 *reinterpret_cast<uint4 *>(base + (size_t)vrow * 8 * K + half * 16) = o;
             }
         }
@@ -921,14 +942,15 @@ __global__ void __launch_bounds__(256) open_columns_ilv_kernel(OpenColsArgs a) {
         for (int j = 0; j < 4; j++) {
             const uint32_t k = wave + 4u * j;
             if (k < d && ok) {
+                const uint64_t lo = ((uint64_t)v[j].y << 32) | v[j].x, hi = ((uint64_t)v[j].w << 32) | v[j].z;
                 if (IMAGE) {
                     uint64_t *dst = reinterpret_cast<uint64_t *>(img + (size_t)(row - r0) * rec_bytes + 8 + k * 32u + half * 16u);
-                    dst[0] = v[j].x;
-                    dst[1] = v[j].y;
+                    dst[0] = lo;
+                    dst[1] = hi;
                 } else {
                     oc_u128_a8 o;
-                    o.x = v[j].x;
-                    o.y = v[j].y;
+                    o.x = lo;
+                    o.y = hi;
                     *reinterpret_cast<oc_u128_a8 *>(recs + (size_t)row * rec_bytes + 8 + k * 32u + half * 16u) = o;
                 }
             }

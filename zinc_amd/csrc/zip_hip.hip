@@ -28,6 +28,7 @@
 #include "kernels_verify.cuh"
 #include "kernels_sumcheck.cuh"
 #include "kernels_spartan.cuh"
+#include "rccl_dyn.h"
 
 using namespace zipk;
 
@@ -86,9 +87,13 @@ struct HintPlan {
     }
 };
 
-static inline bool speculation_default_flag() {
+// zip_ctx::speculate: 0 = never, 1 = only where the library owns a copy of the witness (HOST witnesses: the default --
+// nothing about the caller's buffers changes), 2 = DEVICE witnesses too (opt-in, zip_ctx_set_speculation(ctx, 1): the
+// caller then keeps its device witness valid and unchanged until the handle is freed).  ZIP_HIP_SPECULATE=0 / 1
+// sets the process-wide default to 0 / 2.
+static inline int speculation_default_flag() {
     const char *e = getenv("ZIP_HIP_SPECULATE");
-    return !(e && atoi(e) == 0);
+    return !e ? 1 : atoi(e) == 0 ? 0 : 2;
 }
 
 struct zip_ctx {
@@ -119,7 +124,7 @@ struct zip_ctx {
     std::shared_ptr<bool> alive = std::make_shared<bool>(true);  // false once zip_ctx_destroy has run
     bool profile_commit_only = false;  // zip_ctx_set_profiling(ctx, 2)
     std::shared_ptr<HintPlan> hint_plan;  // what the last hinted commit derived from its column list (memo)
-    bool speculate = speculation_default_flag();  // zip_commit hints itself with the columns of the ctx's last opening
+    int speculate = speculation_default_flag();   // zip_commit hints itself with the columns of the ctx's last opening (0 / 1 / 2, above)
     bool seen_columns = false;                    // ... once an opening (or an explicit hint) has named some
     // chunk arrival counters of the persistent commit kernel: kRingSlots zeroed blocks of kRingStride counters, handed
     // out in turn; every kRingSlots commits the ring is zeroed again (ring_epoch moves: an older handle's counters
@@ -129,7 +134,10 @@ struct zip_ctx {
     // zip_commit_open_begin: pinned staging of the jobs in flight (kJobSlots), and which slots are taken
     unsigned char *job_stage[2] = {nullptr, nullptr};
     bool job_busy[2] = {false, false};
-    bool job_redo = false;  // a pipeline wait gave up while several jobs were in flight: the next one re-gathers too
+    // bumped by every recovery from a timed-out pipeline wait (recover_gather_timeout).  A job enqueued BEFORE a recovery
+    // that another job ran cannot tell any more whether its own waits gave up too (the flag is cleared): it re-gathers.
+    // Jobs enqueued after it are covered by the flag again.
+    uint64_t recover_epoch = 0;
     // make_field memo: the last zip_field seen and what FieldConfig::new made of it (a HostField, kept as bytes here
     // because that type is defined further down)
     zip_field field_cache_in{};
@@ -168,6 +176,7 @@ struct zip_commitment {
     // [bounds[k], bounds[k+1]) is complete (rows, trees, roots) once chunk_done[k] == expected[k].
     std::vector<uint32_t> bounds, expected;
     uint32_t *chunk_done = nullptr;  // device arrival counters (a pool block, or a slot of the ctx's ring)
+    const uint4 *gather_tab = nullptr;  // device, valid during one open: OpenColsArgs.wg_tab (packed handles)
     bool ring_slot = false;
     uint32_t ring_epoch = 0;
     bool consumers_done = false;  // set by zip_job_wait: nothing on the ctx's streams still reads this handle
@@ -853,7 +862,7 @@ bool commit_supports_hint(uint32_t cw) { return cw >= 512; }
 // one pinned / device block per hinted commit: the bitmaps (<= 5.6 KB for cw <= 16384) at offset 0, the
 // column -> openings tables of zip_commit_open (first[cw] | next[n_cols], u16) at kHintTables
 // (packed openings: the wave table at kHintTables, the ranks of the hinted openings at kPackedRanksAt)
-constexpr uint32_t kRingSlots = 64, kRingStride = 16;  // zip_ctx::ring_d
+constexpr uint32_t kRingSlots = 64, kRingChunks = 16, kRingStride = 16;  // zip_ctx::ring_d
 constexpr size_t kHintTables = 8192, kHintBytes = kHintTables + 8 * (8192 / 32) + 4 * 4096 + 64, kPackedRanksAt = kHintTables + 2048;
 // ---- opening hints and packed openings (CommitArgs.need / .pk) -------------------------------------------------
 // Everything a hinted commit derives from its column list, kept per ctx until the list changes (in the prover flow it
@@ -1221,6 +1230,7 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
         a.pk_off1 = c->pk_off[1];
         a.pk_off2 = c->pk_off[2];
         a.pk_rank = c->rank_d + (size_t)first_opening * 4;
+        if (first_opening == 0 && c->plan && n_cols == c->plan->cols.size()) a.wg_tab = c->gather_tab;
     }
     a.out = out_d;
     a.num_rows = ctx->rows_local;
@@ -1348,17 +1358,19 @@ int32_t run_open_columns_pipelined(zip_commitment *c, const uint32_t *cols_dv, u
     const char *force_env = getenv("ZIP_HIP_FORCE_WAIT_TIMEOUT");
     const bool force_timeout = force_env != nullptr;
     const unsigned long long force_ticks = (force_env && atoll(force_env) > 1) ? (unsigned long long)atoll(force_env) : 100000ull;
+    auto wait_for = [&](hipStream_t st, uint32_t *counter, uint32_t target) -> int32_t {
+        LaunchTimer t(ctx, "wait_counter_kernel", st);
+        hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, st, counter, force_timeout ? 0xFFFFFFFFu : target, 0u,
+                           ctx->timeout_flag_d, force_timeout ? force_ticks : 25000000ull /* 0.25 s at 100 MHz */);
+        HIP_TRY(ctx, hipGetLastError());
+        return ZIP_OK;
+    };
     for (size_t k = 0; k + 1 < c->bounds.size(); k++) {
         hipStream_t st = gs[k & 1];
-        {
-            LaunchTimer t(ctx, "wait_counter_kernel", st);
-            hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, st, c->chunk_done + k,
-                               force_timeout ? 0xFFFFFFFFu : c->expected[k], 0u, ctx->timeout_flag_d,
-                               force_timeout ? force_ticks : 25000000ull /* 0.25 s at 100 MHz */);
-            HIP_TRY(ctx, hipGetLastError());
-        }
-        int32_t rc = run_open_columns(c, cols_dv, n_cols, out_d, c->bounds[k], c->bounds[k + 1], 0, st,
-                                      /*alone=*/k + 2 == c->bounds.size());
+        int32_t rc = wait_for(st, c->chunk_done + k, c->expected[k]);
+        if (rc) return rc;
+        rc = run_open_columns(c, cols_dv, n_cols, out_d, c->bounds[k], c->bounds[k + 1], 0, st,
+                              /*alone=*/k + 2 == c->bounds.size());
         if (rc) return rc;
     }
     if (gs[1] != gs[0]) {
@@ -1385,6 +1397,7 @@ int32_t recover_gather_timeout(zip_commitment *c, const uint32_t *cols_dv, uint3
     HIP_TRY(ctx, stream_wait(ctx->stream));
     const bool timed_out = ctx->timeout_flag_h && *ctx->timeout_flag_h;
     if (!timed_out && !force) return ZIP_OK;
+    if (timed_out) ctx->recover_epoch++;
     if (ctx->timeout_flag_h) *ctx->timeout_flag_h = 0;
     int32_t rc = wait_ready(c, ctx->stream);
     if (rc) return rc;
@@ -2088,7 +2101,7 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
             // chunks of two rounds, at most 16 -- there the gathers have slack (each waits ~0.3 ms for its chunk) and
             // what ends a step is the last chunk's gather alone: 5.733 / 5.693 against 5.805 / 5.782 ms per step.
             if (sched.empty() && !ctx->n_chunks && rounds >= 12) {
-                const uint32_t n = rounds >= 24 ? std::min(kRingStride, rounds / 2) : std::min(8u, rounds / 3), base = rounds / n;
+                const uint32_t n = rounds >= 24 ? std::min(kRingChunks, rounds / 2) : std::min(8u, rounds / 3), base = rounds / n;
                 for (uint32_t k = 0; k + 1 < n; k++) sched.push_back(base);
                 sched.push_back(rounds - base * (n - 1));
             }
@@ -2188,7 +2201,7 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
         // (a single chunk is published through its counter too: the gather then starts ~5 us after the commit kernel's
         // last workgroup has published instead of a cross-stream event's ~20 us after the kernel has ended -- 2^20)
         if (with_merkle && (nch > 1 || (hint_cols && R >= ctx->num_cus))) {
-            if (nch <= kRingStride && !ctx->ring_d) {  // first pipelined commit of this ctx
+            if (nch <= kRingChunks && !ctx->ring_d) {  // first pipelined commit of this ctx
                 if (hipMalloc((void **)&ctx->ring_d, (size_t)kRingSlots * kRingStride * 4) != hipSuccess ||
                     hipMemset(ctx->ring_d, 0, (size_t)kRingSlots * kRingStride * 4) != hipSuccess) {
                     if (ctx->ring_d) (void)hipFree(ctx->ring_d);
@@ -2196,7 +2209,7 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
                     (void)hipGetLastError();
                 }
             }
-            if (nch <= kRingStride && ctx->ring_d) {
+            if (nch <= kRingChunks && ctx->ring_d) {
                 if (ctx->ring_next == kRingSlots) {
                     // every slot has been used: nobody may still poll one (the streams are idle between calls; a kept
                     // handle notices the new epoch), then one memset for the next kRingSlots commits
@@ -2253,15 +2266,19 @@ static int32_t launch_witness_digest(zip_ctx *ctx, const int64_t *evals_d, size_
 // the commit cannot be told the columns, but in that flow they never change -- they are a function of the field and
 // the codeword length -- so a ctx that has seen an opening hints its next plain commits with THAT column list.  The
 // open that follows finds exactly what it reads (byte-identical proof, the hinted commit's speed); anything else asked
-// of the handle completes it first, transparently (rematerialize).  zip_ctx_set_speculation(ctx, 0) or
-// ZIP_HIP_SPECULATE=0 switches it off.
+// of the handle completes it first, transparently (rematerialize).  By default only for HOST witnesses (what the Rust
+// binding passes: the library re-runs from its OWN copy, the contract of zip_commit is untouched); for DEVICE witnesses
+// only after zip_ctx_set_speculation(ctx, 1) -- the handle then reads the caller's array again when it is completed
+// (round-3 advisor finding: that lifetime rule must not arrive unasked).  zip_ctx_set_speculation(ctx, 0) or
+// ZIP_HIP_SPECULATE=0 switches it off altogether.
 int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_kind evals_kind,
                    int32_t with_merkle, uint8_t *roots_out, zip_commitment **out) {
     if (!ctx || !out) return ZIP_ERR_NULL;
     std::shared_ptr<HintPlan> plan;
     {
         std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
-        if (with_merkle && ctx->speculate && ctx->seen_columns && ctx->hint_plan && ctx->hint_plan->cw == ctx->p.codeword_len &&
+        if (with_merkle && (ctx->speculate == 2 || (ctx->speculate == 1 && evals_kind == ZIP_MEM_HOST)) && ctx->seen_columns &&
+            ctx->hint_plan && ctx->hint_plan->cw == ctx->p.codeword_len &&
             !ctx->hint_plan->cols.empty() && commit_supports_hint(ctx->p.codeword_len))
             plan = ctx->hint_plan;
     }
@@ -2286,7 +2303,7 @@ int32_t zip_commit(zip_ctx *ctx, const int64_t *evals, size_t n_evals, zip_mem_k
 int32_t zip_ctx_set_speculation(zip_ctx *ctx, int32_t on) {
     if (!ctx) return ZIP_ERR_NULL;
     std::lock_guard<std::recursive_mutex> api_lock(ctx->api_mu);
-    ctx->speculate = on != 0;
+    ctx->speculate = on ? 2 : 0;
     return ZIP_OK;
 }
 
@@ -2669,9 +2686,25 @@ static int32_t open_enqueue(zip_commitment *c, const int64_t *evals_d, const int
         si.src[3] = order.data();
         si.bytes[3] = (size_t)n_cols * 4;
     }
+    // packed handles: what gather workgroup x needs (opening, column, the four packed ranks) in one 16-byte entry
+    std::vector<uint32_t> wg_tab;
+    if (c->packed && c->plan && c->plan->cols.size() == n_cols && c->plan->own_ranks.size() == (size_t)n_cols * 4 && n_cols <= 65536) {
+        wg_tab.resize((size_t)n_cols * 4);
+        for (uint32_t b = 0; b < n_cols; b++) {
+            const uint32_t i = order.empty() ? b : order[b];
+            const uint16_t *r = c->plan->own_ranks.data() + (size_t)i * 4;
+            wg_tab[4 * b] = i | (cols[i] << 16);
+            wg_tab[4 * b + 1] = (uint32_t)r[0] | ((uint32_t)r[1] << 16);
+            wg_tab[4 * b + 2] = (uint32_t)r[2] | ((uint32_t)r[3] << 16);
+            wg_tab[4 * b + 3] = 0;
+        }
+        si.src[4] = wg_tab.data();
+        si.bytes[4] = wg_tab.size() * 4;
+    }
     unsigned char *sb;
     if ((rc = stage_small(ctx, si, small, &sb, own_stage, own_stage ? kJobStageBytes : 0))) return rc;
     c->gather_order = order.empty() ? nullptr : reinterpret_cast<const uint32_t *>(sb + si.off[3]);  // (lives in `small`)
+    c->gather_tab = wg_tab.empty() ? nullptr : reinterpret_cast<const uint4 *>(sb + si.off[4]);
     st.cols_dv = reinterpret_cast<const uint32_t *>(sb + si.off[2]);
     st.n_cols = n_cols;
     st.openings_d = out_d + u_bytes;
@@ -2734,7 +2767,8 @@ static int32_t open_enqueue(zip_commitment *c, const int64_t *evals_d, const int
 // synchronises: the small host inputs (coeffs, cols, q0) have been consumed, every launch has run
 static int32_t open_finish(zip_commitment *c, OpenState &st, bool force_regather = false) {
     const int32_t rc = recover_gather_timeout(c, st.cols_dv, st.n_cols, st.openings_d, force_regather);
-    c->gather_order = nullptr;  // the table lives in st.small
+    c->gather_order = nullptr;  // the tables live in st.small
+    c->gather_tab = nullptr;
     return rc;
 }
 static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int64_t *coeffs, const uint32_t *cols,
@@ -2743,6 +2777,7 @@ static int32_t open_device(zip_commitment *c, const int64_t *evals_d, const int6
     int32_t rc = open_enqueue(c, evals_d, coeffs, cols, n_cols, q0_mont, hf, out_d, st);
     if (rc) {
         c->gather_order = nullptr;
+        c->gather_tab = nullptr;
         return rc;
     }
     return open_finish(c, st);
@@ -2879,6 +2914,7 @@ struct zip_job {
     OpenState *st = nullptr;
     hipEvent_t finished = nullptr;  // behind the last launch of the open on the main stream
     int slot = -1;
+    uint64_t epoch = 0;  // zip_ctx::recover_epoch when the job was enqueued
 };
 int32_t zip_commit_open_begin(zip_ctx *ctx, const int64_t *evals_d, size_t n_evals, const int64_t *coeffs, const uint32_t *cols,
                               uint32_t n_cols, const uint64_t *q0_mont, const zip_field *field, uint8_t *proof_out_d,
@@ -2919,6 +2955,7 @@ int32_t zip_commit_open_begin(zip_ctx *ctx, const int64_t *evals_d, size_t n_eva
     if (rc) {  // (the destructors drain what was enqueued)
         const std::string keep = ctx->last_error;
         j->c->gather_order = nullptr;
+        j->c->gather_tab = nullptr;
         delete j->st;
         zip_commitment_free(j->c);
         if (j->finished) ctx->dep_event_pool.push_back(j->finished);
@@ -2928,6 +2965,7 @@ int32_t zip_commit_open_begin(zip_ctx *ctx, const int64_t *evals_d, size_t n_eva
     }
     ctx->job_busy[slot] = true;
     j->slot = slot;
+    j->epoch = ctx->recover_epoch;
     *out = j;
     return ZIP_OK;
 }
@@ -2940,12 +2978,12 @@ int32_t zip_job_wait(zip_job *j, uint8_t *roots_out) {
     int32_t rc = ZIP_OK;
     hipError_t e = event_wait(j->finished);  // NOT the stream: the next job may already be queued behind this one
     if (e != hipSuccess) rc = fail(ctx, ZIP_ERR_HIP, "job failed: %s", hipGetErrorString(e));
-    if (!rc && ((ctx->timeout_flag_h && *ctx->timeout_flag_h) || ctx->job_redo)) {
+    const bool forced = j->epoch < ctx->recover_epoch;  // a recovery ran (and cleared the flag) after this job was enqueued
+    if (!rc && ((ctx->timeout_flag_h && *ctx->timeout_flag_h) || forced)) {
         // a pipeline wait gave up (counter collection serialises the streams): everything in flight is redone.  The
-        // first job to notice drains the streams and clears the flag; the job that was queued behind it cannot tell
-        // any more whether ITS waits gave up too, so it re-gathers unconditionally (job_redo).
-        const bool forced = ctx->job_redo;
-        ctx->job_redo = ctx->job_busy[0] && ctx->job_busy[1];
+        // first job to notice drains the streams and clears the flag; a job that was already queued then cannot tell
+        // any more whether ITS waits gave up too, so it re-gathers unconditionally.  Jobs enqueued after the recovery
+        // are not affected (the flag covers their own waits): no sticky state.
         rc = open_finish(j->c, *j->st, forced);  // (synchronises the streams)
     }
     if (!rc && roots_out) {
@@ -2955,6 +2993,7 @@ int32_t zip_job_wait(zip_job *j, uint8_t *roots_out) {
     // everything of this job on the main and the fold stream has run: nothing to drain, nothing to wait for
     const std::string keep = ctx->last_error;
     j->c->gather_order = nullptr;
+    j->c->gather_tab = nullptr;
     if (!rc) {
         j->st->cscr.drain = nullptr;
         j->c->consumers_done = true;
@@ -3005,12 +3044,7 @@ struct zip_mctx {
 // librccl is bound at run time (dlopen), only by a zip_mctx over several distinct devices: libzip_hip.so itself has no
 // RCCL dependency, and a process that already carries an RCCL (PyTorch's) gets that copy.
 namespace rccl {
-typedef int (*comm_init_all_t)(void **comms, int ndev, const int *devlist);
-typedef int (*comm_destroy_t)(void *comm);
-typedef int (*group_t)(void);
-typedef int (*all_gather_t)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t st);
-typedef int (*broadcast_t)(const void *send, void *recv, size_t count, int dtype, int root, void *comm, hipStream_t st);
-typedef const char *(*err_str_t)(int);
+// (the function-pointer types: rccl_dyn.h -- RCCL's own prototypes where its header exists)
 struct Api {
     void *lib = nullptr;
     comm_init_all_t comm_init_all = nullptr;
@@ -3021,12 +3055,11 @@ struct Api {
     err_str_t err_str = nullptr;
     bool ok = false;
 };
-constexpr int kUint8 = 1;  // ncclUint8 (= ncclChar + 1; rccl.h ncclDataType_t)
 static Api &api() {
     static Api a;
     static std::once_flag once;
     std::call_once(once, [] {
-        if (getenv("ZIP_HIP_NO_RCCL")) return;
+        if (getenv("ZIP_HIP_NO_RCCL")) return;  // (per process; per zip_mctx: ZIP_HIP_MCTX_FORCE_NO_RCCL, zip_mctx_create)
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (a.lib) break;
@@ -3074,7 +3107,7 @@ void zip_mctx_destroy(zip_mctx *m) {
         }
     }
     for (void *c : m->nccl_comm)
-        if (c && rccl::api().ok) (void)rccl::api().comm_destroy(c);
+        if (c && rccl::api().ok) (void)rccl::api().comm_destroy(static_cast<rccl::comm_t>(c));
     for (zip_ctx *ctx : m->shard) zip_ctx_destroy(ctx);
     delete m;
 }
@@ -3111,7 +3144,9 @@ int32_t zip_mctx_create(const zip_params *p, int32_t n_devices, const int32_t *d
             if (!rc && s > 0 && m->shard[s]->device != m->shard[0]->device) {
                 int can = 0;
                 (void)hipSetDevice(m->shard[0]->device);
-                if (hipDeviceCanAccessPeer(&can, m->shard[0]->device, m->shard[s]->device) == hipSuccess && can) {
+                // (ZIP_HIP_MCTX_FORCE_NO_PEER=1: as on a box whose devices cannot map each other -- hipMemcpyPeerAsync
+                // then stages through the host; same bytes)
+                if (!getenv("ZIP_HIP_MCTX_FORCE_NO_PEER") && hipDeviceCanAccessPeer(&can, m->shard[0]->device, m->shard[s]->device) == hipSuccess && can) {
                     hipError_t e = hipDeviceEnablePeerAccess(m->shard[s]->device, 0);
                     if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) rc = ZIP_ERR_HIP;
                     (void)hipGetLastError();
@@ -3124,12 +3159,15 @@ int32_t zip_mctx_create(const zip_params *p, int32_t n_devices, const int32_t *d
         bool distinct = true;
         for (uint32_t s = 0; s < G; s++)
             for (uint32_t t = 0; t < s; t++) distinct &= devices[s] != devices[t];
-        if (distinct && rccl::api().ok) {
+        // (ZIP_HIP_MCTX_FORCE_NO_RCCL=1: as on a box without a usable librccl -- the roots travel as device copies)
+        if (distinct && !getenv("ZIP_HIP_MCTX_FORCE_NO_RCCL") && rccl::api().ok) {
             m->nccl_comm.assign(G, nullptr);
             std::vector<int> devs(devices, devices + G);
-            const int e = rccl::api().comm_init_all(m->nccl_comm.data(), (int)G, devs.data());
+            std::vector<rccl::comm_t> comms(G, nullptr);
+            const int e = (int)rccl::api().comm_init_all(comms.data(), (int)G, devs.data());
+            for (uint32_t s = 0; s < G; s++) m->nccl_comm[s] = comms[s];
             if (e != 0) {  // (not fatal: the roots then travel as peer copies; zip_mctx_roots_path says which)
-                m->last_error = std::string("ncclCommInitAll failed: ") + (rccl::api().err_str ? rccl::api().err_str(e) : "?");
+                m->last_error = std::string("ncclCommInitAll failed: ") + (rccl::api().err_str ? rccl::api().err_str((rccl::result_t)e) : "?");
                 m->nccl_comm.clear();
             }
         }
@@ -3314,26 +3352,27 @@ int32_t zip_mctx_commit_open(zip_mctx *m, const int64_t *evals, const int64_t *c
         bool done = false;
         if (!m->nccl_comm.empty()) {
             rccl::Api &N = rccl::api();
-            int e = N.group_start();
+            int e = (int)N.group_start();
             for (uint32_t s = 0; s < G && e == 0; s++) {
                 zip_ctx *ctx = m->shard[s];
                 (void)hipSetDevice(ctx->device);
                 if (even) {
-                    e = N.all_gather(com[s]->roots, m->roots_all[s], (size_t)ctx->rows_local * 32, rccl::kUint8, m->nccl_comm[s], ctx->s_commit);
+                    e = (int)N.all_gather(com[s]->roots, m->roots_all[s], (size_t)ctx->rows_local * 32, rccl::kUint8,
+                                          static_cast<rccl::comm_t>(m->nccl_comm[s]), ctx->s_commit);
                 } else {  // uneven blocks of rows (3 shards): one broadcast per owner
                     for (uint32_t root = 0; root < G && e == 0; root++) {
                         zip_ctx *rc_ = m->shard[root];
-                        e = N.broadcast(com[root]->roots, m->roots_all[s] + (size_t)rc_->p.row_begin * 32, (size_t)rc_->rows_local * 32,
-                                        rccl::kUint8, (int)root, m->nccl_comm[s], ctx->s_commit);
+                        e = (int)N.broadcast(com[root]->roots, m->roots_all[s] + (size_t)rc_->p.row_begin * 32, (size_t)rc_->rows_local * 32,
+                                             rccl::kUint8, (int)root, static_cast<rccl::comm_t>(m->nccl_comm[s]), ctx->s_commit);
                     }
                 }
             }
-            const int e2 = N.group_end();
+            const int e2 = (int)N.group_end();
             if (e == 0 && e2 == 0) {
                 done = true;
                 m->roots_path = "rccl";
             } else {
-                m->last_error = std::string("RCCL roots gather failed (falling back to copies): ") + (N.err_str ? N.err_str(e ? e : e2) : "?");
+                m->last_error = std::string("RCCL roots gather failed (falling back to copies): ") + (N.err_str ? N.err_str((rccl::result_t)(e ? e : e2)) : "?");
             }
         }
         if (!done) {
