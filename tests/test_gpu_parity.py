@@ -512,6 +512,38 @@ def test_commit_open_in_one_call_is_byte_identical(cabi, geometry, device_out, p
     assert none is None and np.array_equal(proof2, proof_o)
 
 
+@pytest.mark.parametrize("num_vars", [16, 18, 20])
+@pytest.mark.parametrize("classes", ["1", "2", "4"])
+def test_single_round_commit_in_priority_classes(cabi, num_vars, classes, monkeypatch):
+    """A commit of ONE round whose workgroups share their CUs (2^16: 8 per CU, 2^18: 8, 2^20: 4) is published in classes
+    of workgroups at different wave priorities (CommitArgs.classes; ZIP_HIP_CLASSES = 1: off, 2, 4), each class a chunk
+    of consecutive rows gathered on its own.  Same roots, same proof bytes as the oracle, device witness, poisoned output."""
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("ZIP_HIP_CLASSES", classes)
+    z = orc.Zip(num_vars)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    evals = _witness(num_vars, seed=131)
+    point = orc.point_to_field(f, np.arange(2, num_vars + 2, dtype=np.int64))
+    rows_o, layers_o, roots_o = z.commit(evals)
+    proof_o, cols, coeffs = z.open(f, evals, rows_o, layers_o, point, orc.new_transcript())
+    lr = z.num_rows.bit_length() - 1
+    q0 = orc.build_eq_x_r(f, point[num_vars - lr:])
+    ctx = _ctx(cabi, z)
+    d = torch.from_numpy(evals).cuda()
+    for _ in range(2):
+        out = torch.full((proof_o.size,), 0x5C, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        _, roots, com = ctx.commit_open(d, coeffs, cols, q0, zf, out=out, keep=True)
+        ctx.synchronize()
+        assert np.array_equal(roots, roots_o)
+        bad = np.flatnonzero(out.cpu().numpy() != proof_o)
+        assert bad.size == 0, f"{bad.size} proof bytes differ, first at {bad[:8]}"
+        rows, _, _ = com.download()  # the handle completes itself (full re-run with the same row mapping)
+        assert np.array_equal(rows, rows_o)
+        com.free()
+
+
 @pytest.mark.parametrize("geometry", [(16, None), (20, None), (17, (8192, 16, 16384))])
 @pytest.mark.parametrize("pattern", ["min", "max", "alternating", "runs"])
 def test_commit_extreme_witnesses(cabi, geometry, pattern):

@@ -60,6 +60,11 @@ struct CommitArgs {
     uint32_t pk_stride, pk_off0, pk_off1, pk_off2;  // bytes: row stride, start of the three node sections (of ONE row)
     const uint32_t *pk_tab;     // [waves][16] words: per wave the 32 16-bit section ranks its lanes' stores start at
     uint32_t *chunk_done;       // [chunks] arrival counters, or null
+    // A commit of ONE round with several workgroups per CU (2^20: four of 256 threads): 1 = as always; k > 1 = k classes
+    // of workgroups (commit_class) at DIFFERENT wave priorities, so that the workgroups sharing a CU finish one after the
+    // other instead of together; class c's rows are chunk c (chunk_done[c]), whose openings are gathered beside the
+    // hashing of the classes still at work -- a single round has no later round for a gather to run beside.
+    uint32_t classes;
     // Opening hint (zip_commit_hinted): bitmaps of what an open of the hinted columns will ever read, or null =
     // store everything.  Words: [V: cw bits, entry j is opened][N0: cw bits][N1: cw/2][N2: cw/4], N_l bit i = node i
     // of level l is the sibling of an opened path ((i ^ 1) == c >> l for an opened column c).  Levels >= 3 are
@@ -168,8 +173,19 @@ constexpr uint32_t kNodeWords = ILV ? 32u : 8u;
 // speed only), so XCD x takes the x-th eighth of the round's rows, in order: the four rows of an interleave group
 // (and the 32 rows of a gather workgroup) are then produced at the same time by workgroups that share an L2, where
 // their quarter-line stores meet before they are written back.  Any bijection of [0, G) is correct.
-__device__ __forceinline__ uint32_t round_slot(uint32_t b, uint32_t G) {
-    return (G & 7u) ? b : (b & 7u) * (G >> 3) + (b >> 3);
+// `classes` > 1 (CommitArgs.classes: a commit of ONE round whose workgroups share their CUs, 2^20): the l-th workgroup of
+// an XCD belongs to class l / (G / 8 / classes) -- with round-robin placement the workgroups that share a CU are one of
+// each class -- and class k takes the k-th part of the rows, each XCD a contiguous piece of it: a class is a chunk of
+// consecutive rows that is published, and gathered, on its own (commit_class).
+__device__ __forceinline__ uint32_t round_slot(uint32_t b, uint32_t G, uint32_t classes = 1) {
+    if (G & 7u) return b;
+    const uint32_t x = b & 7u, l = b >> 3;
+    if (classes <= 1u) return x * (G >> 3) + l;
+    const uint32_t per = (G >> 3) / classes, k = l / per;
+    return k * (G / classes) + x * per + (l - k * per);
+}
+__device__ __forceinline__ uint32_t commit_class(uint32_t b, uint32_t G, uint32_t classes) {
+    return classes <= 1u ? 0u : (b >> 3) / ((G >> 3) / classes);
 }
 
 // Hash of the complete subtree over the 2^LVL inputs [E0, E0 + 2^LVL) of one thread,
@@ -400,7 +416,7 @@ __device__ __forceinline__ void upper_stage(const CommitArgs &a, uint32_t first,
     const uint32_t cw = a.cw, depth = 31u - __builtin_clz(cw);
     const uint32_t u_shift = depth - (lvl - 1u) - nl;  // log2(groups per row)
     const uint32_t total = nrows_c << u_shift;
-    const uint32_t slot0 = round_slot(blockIdx.x, gridDim.x);
+    const uint32_t slot0 = round_slot(blockIdx.x, gridDim.x, a.classes);
     for (uint32_t idx = lane; idx < total; idx += nlanes) {
         const uint32_t ri = idx >> u_shift, i = idx & ((1u << u_shift) - 1u);
         const uint32_t r = slot0 + (first + ri) * gridDim.x;
@@ -567,7 +583,7 @@ struct ChunkFinisher {
 #endif
         if (depth == 0 && tid == 0) {  // a one-leaf tree: the root is the leaf hash
             for (uint32_t ri = 0; ri < nrows_c; ri++) {
-                const uint32_t r = round_slot(blockIdx.x, gridDim.x) + (first + ri) * gridDim.x;
+                const uint32_t r = round_slot(blockIdx.x, gridDim.x, a.classes) + (first + ri) * gridDim.x;
                 uint32_t h[8];
                 load_hash(a.layers + (size_t)r * (2u * cw) * 8, h);  // (never interleaved: packed commits have depth >= 3)
                 store_hash(a.roots + (size_t)r * 8, h);
@@ -690,10 +706,18 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
 #endif
     uint32_t round = 0;
     ChunkCursor cc;
+    if (a.classes > 1u) {  // (one round: the class is the chunk; the earlier the class, the higher its waves' priority)
+        const uint32_t c = commit_class(blockIdx.x, gridDim.x, a.classes);
+        cc.index = c;
+        const uint32_t prio = (a.classes - 1u - c) * 3u / (a.classes - 1u);  // 3 .. 0 over the classes
+        if (prio == 3u) __builtin_amdgcn_s_setprio(3);
+        else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
+        else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
+    }
     ChunkFinisher<HASH, MODE == kStorePacked> fin;
     fin.init(reinterpret_cast<uint32_t *>(rowbuf + row_len), tid0);
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    for (uint32_t row = round_slot(blockIdx.x, gridDim.x); row < a.num_rows; row += gridDim.x, round++) {
+    for (uint32_t row = round_slot(blockIdx.x, gridDim.x, a.classes); row < a.num_rows; row += gridDim.x, round++) {
 #ifdef ZIPK_DEBUG_STAMPS
         ph_t = wall_clock64();
 #endif
@@ -922,7 +946,7 @@ __global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
     ChunkFinisher<HASH, MODE == kStorePacked> fin;
     fin.init(reinterpret_cast<uint32_t *>(ghi + T), tid0);
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    for (uint32_t row = round_slot(blockIdx.x, gridDim.x); row < a.num_rows; row += gridDim.x, round++) {
+    for (uint32_t row = round_slot(blockIdx.x, gridDim.x, a.classes); row < a.num_rows; row += gridDim.x, round++) {
         fin.top_of_row();
         const uint32_t z = opaque_zero(row);
         const uint32_t tid = tid0 + z;

@@ -2126,7 +2126,31 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
                 if (k < nch) r += sched[k];
             }
         }
+        // ONE round of workgroups that share their CUs (2^20: 1024 rows, four 256-thread workgroups per CU) has no later
+        // round for a gather to run beside: the workgroups are split into classes at different wave priorities instead
+        // (CommitArgs.classes) -- class c, a contiguous c-th part of the rows, finishes and is published while the
+        // later classes still hash, and its openings are gathered beside them.  Measured at 2^20 (round 4, one box,
+        // twice each): two classes 0.273 / 0.278, four 0.276 / 0.277, none 0.283 / 0.283 ms per step -- the priorities
+        // stagger the classes less than hoped (class 0 of four is published at 116 of the kernel's 157 us,
+        // profiles/EXPERIMENTS.md), so the gain is the one gather that overlaps.  Default two; ZIP_HIP_CLASSES=1: off.
+        uint32_t classes = 1;
+        {
+            const int knob_classes = getenv("ZIP_HIP_CLASSES") ? atoi(getenv("ZIP_HIP_CLASSES")) : 0;  // (per call: the tests flip it)
+            const uint32_t per_cu = commit_wgs_per_cu(geom);
+            if (with_merkle && hint_cols && commit_supports_hint(cw) && rounds == 1 && R == G && per_cu >= 2 && G % 8 == 0 &&
+                !ctx->n_chunks && knob_classes != 1) {
+                classes = knob_classes > 1 ? (uint32_t)knob_classes : std::min(2u, per_cu);
+                while (classes > 1 && ((G / 8) % classes || classes > per_cu)) classes--;
+            }
+            if (classes > 1) {
+                nch = classes;
+                chunk_ends = 0;
+                c->bounds.resize(nch + 1);
+                for (uint32_t k = 0; k <= nch; k++) c->bounds[k] = k * (G / classes);
+            }
+        }
         CommitArgs a{};
+        a.classes = classes;
         a.evals = evals_d;
         a.perm1 = ctx->perm1_d;
         a.perm2 = ctx->perm2_d;
@@ -2232,6 +2256,8 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
             a.chunk_done = c->chunk_done;
             c->expected.resize(nch);
             for (uint32_t k = 0; k < nch; k++) c->expected[k] = (R - c->bounds[k]) < G ? (R - c->bounds[k]) : G;
+            if (classes > 1)  // (a class is G / classes workgroups, each with one row)
+                for (uint32_t k = 0; k < nch; k++) c->expected[k] = G / classes;
         }
         if (e != hipSuccess) { rc = fail(ctx, ZIP_ERR_HIP, "commit setup failed: %s", hipGetErrorString(e)); break; }
         rc = with_merkle ? dispatch_commit<true>(ctx, a, G, ctx->s_commit) : dispatch_commit<false>(ctx, a, G, ctx->s_commit);
