@@ -1256,11 +1256,14 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
     } else {
         // (2.5 KB of slack: LDS is handed out in granules -- 24 records = 10.7 KB did NOT get in beside 148.8 KB)
         while (rpb > 8 && rpb * rec + 2560 > free_lds) rpb -= 8;
-        // the LAST chunk's gather runs after the commit kernel has ended, with the CU's whole LDS: 96 records per
-        // workgroup move more bytes per workgroup lifetime (0.735 against 0.825 ms for 4096 rows alone at 2^24) -- unless
-        // another job is in flight on the ctx (zip_commit_open_begin: the NEXT job's commit kernel is then resident when
-        // this gather runs, and 40 KB of LDS would wait for that kernel to end)
-        if (alone && rpb == 32 && row_hi - row_lo >= 96 && 96 * rec <= 48u * 1024u && !(ctx->job_busy[0] || ctx->job_busy[1])) rpb = 96;
+        // the LAST chunk's gather runs after the commit kernel has ended, with the CU's whole LDS.  On the natural layout 96
+        // records per workgroup moved more bytes per workgroup lifetime (0.735 against 0.825 ms for 4096 rows alone at
+        // 2^24, round 3) -- unless another job is in flight on the ctx (zip_commit_open_begin: the NEXT job's commit kernel
+        // is then resident when this gather runs, and 40 KB of LDS would wait for that kernel to end).  The row-interleaved
+        // gather of a packed handle is the other way round: alone, 32 rows per workgroup take 0.094 ms per launch, 64
+        // 0.106, 96 0.120, 128 0.166 (tools/exp_r4_alone_gather.sh), and the step ends 27 us sooner with 32 for the last
+        // chunk too (1.559-1.561 against 1.580-1.594 ms, alternated three times): no bump there.
+        if (alone && !c->packed && rpb == 32 && row_hi - row_lo >= 96 && 96 * rec <= 48u * 1024u && !(ctx->job_busy[0] || ctx->job_busy[1])) rpb = 96;
     }
     a.rows_per_block = (row_hi - row_lo) < rpb ? (row_hi - row_lo) : rpb;
     static const int knob_prio = getenv("ZIP_HIP_GATHER_PRIO") ? atoi(getenv("ZIP_HIP_GATHER_PRIO")) : 1;
