@@ -846,6 +846,35 @@ def test_multi_device_context_on_the_2pow26_geometry(cabi, shards):
     m.close()
 
 
+@pytest.mark.parametrize("knob", ["ZIP_HIP_MCTX_FORCE_NO_RCCL", "ZIP_HIP_MCTX_FORCE_NO_PEER", "both"])
+@pytest.mark.parametrize("shards", [1, 3, 4])
+def test_multi_device_context_without_rccl_or_peer_access(cabi, shards, knob, monkeypatch):
+    """What zip_mctx does on a box whose librccl is missing / refuses (ZIP_HIP_MCTX_FORCE_NO_RCCL: the roots travel as
+    device copies -- also for ONE shard, which otherwise takes the real one-rank RCCL path) or whose devices cannot map
+    each other (ZIP_HIP_MCTX_FORCE_NO_PEER: no hipDeviceEnablePeerAccess; hipMemcpyPeerAsync stages): the same bytes.
+    (Round-3 verdict: the first real 8-GPU run must not be the first time these branches execute.)"""
+    for k in (["ZIP_HIP_MCTX_FORCE_NO_RCCL", "ZIP_HIP_MCTX_FORCE_NO_PEER"] if knob == "both" else [knob]):
+        monkeypatch.setenv(k, "1")
+    num_vars = 16
+    z = orc.Zip(num_vars)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    evals = _witness(num_vars, seed=47)
+    point = orc.point_to_field(f, np.arange(2, num_vars + 2, dtype=np.int64))
+    rows_o, layers_o, roots_o = z.commit(evals)
+    proof_o, cols, coeffs = z.open(f, evals, rows_o, layers_o, point, orc.new_transcript())
+    lr = z.num_rows.bit_length() - 1
+    q0 = orc.build_eq_x_r(f, point[num_vars - lr:])
+    m = cabi.ZipMultiContext(num_vars, z.perm1, z.perm2, [0] * shards)
+    proof, roots = m.commit_open(evals, coeffs, cols, q0, zf)
+    assert np.array_equal(roots, roots_o) and np.array_equal(proof, proof_o)
+    want_path = "copies" if (shards > 1 or knob != "ZIP_HIP_MCTX_FORCE_NO_PEER") else "rccl"
+    assert m.roots_path() == want_path, m.roots_path()
+    for sh in range(shards):
+        assert np.array_equal(_device_bytes(m.roots_ptr(sh), z.num_rows * 32).reshape(z.num_rows, 32), roots_o), sh
+    m.close()
+
+
 @pytest.mark.parametrize("num_vars", [12, 16, 18])
 @pytest.mark.parametrize("shards", [1, 2, 3, 4, 8])
 def test_multi_device_context_proof_equals_unsharded(cabi, num_vars, shards):
