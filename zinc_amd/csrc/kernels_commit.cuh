@@ -549,11 +549,60 @@ struct ChunkFinisher {
         }
     }
 
-    // behind the row loop: the rest of the last chunk, through the same staged hand-over between the oldest waves.  (Its own
-    // call site, OUTSIDE the loop: inlined a second time inside it, after_hash cost the 16-entry kernel 18 registers.)
-    __device__ __forceinline__ void after_loop(const CommitArgs &a, uint32_t wave, uint32_t lane, uint32_t T) {
+    // behind the row loop: the rest of the LAST chunk.  Nothing is left to hide it behind and every wave is free, so the
+    // levels go one by one with ALL lanes and the nodes stay in LDS between them (the row buffers are dead by now): one
+    // read of the head's nodes from L2, then per level a conflict-free LDS read, one compression, an LDS write and the
+    // store to the tree -- ~2 us a level where the staged hand-over of after_hash (made for ONE free wave per SIMD) pays
+    // a flag, an L2 round trip and three lone-wave compressions per two levels.  `lds`: scratch of lds_bytes (16-byte
+    // aligned); too small for this chunk's nodes -> the staged path.
+    __device__ __forceinline__ void after_loop(const CommitArgs &a, uint32_t wave, uint32_t lane, uint32_t T, unsigned char *lds,
+                                               uint32_t lds_bytes) {
         if (!(HASH && pending)) return;
         __syncthreads();  // (the head's stores are in L2: what top_of_row + a row's barriers do otherwise)
+        const uint32_t cw = a.cw, depth = 31u - __builtin_clz(cw);
+        const uint32_t tid = lane + 64u * wave;
+        const uint32_t w_in0 = cw >> (p_lvl - 1u);           // nodes per row at the level below p_lvl
+        const uint32_t n_in0 = p_nrows * w_in0;
+#ifndef ZIPK_NO_LDS_TOP
+        if (p_lvl <= depth && (n_in0 + n_in0 / 2u) * 32u <= lds_bytes && n_in0 >= 2u) {
+            constexpr uint32_t NW = kNodeWords<ILV>;
+            pending = false;
+            uint4 *bufA = reinterpret_cast<uint4 *>(lds), *bufB = bufA + 2u * n_in0;  // 2 uint4 per node
+            const uint32_t slot0 = round_slot(blockIdx.x, gridDim.x, a.classes);
+            const uint32_t sh0 = 31u - __builtin_clz(w_in0);
+            for (uint32_t idx = tid; idx < n_in0; idx += T) {
+                const uint32_t ri = idx >> sh0, i = idx & (w_in0 - 1u);
+                const uint32_t r = slot0 + (p_first + ri) * gridDim.x;
+                const uint4 *src = reinterpret_cast<const uint4 *>(tree_of<ILV>(a.layers, cw, r) + ((size_t)level_off(cw, p_lvl - 1u) + i) * NW);
+                bufA[2u * idx] = src[0];
+                bufA[2u * idx + 1u] = src[1];
+            }
+            __syncthreads();
+            uint4 *in = bufA, *out = bufB;
+            for (uint32_t lvl = p_lvl; lvl <= depth; lvl++) {
+                const uint32_t w = cw >> lvl, sh = 31u - __builtin_clz(w), m = p_nrows * w;
+                for (uint32_t idx = tid; idx < m; idx += T) {
+                    const uint32_t ri = idx >> sh, i = idx & (w - 1u);
+                    const uint32_t r = slot0 + (p_first + ri) * gridDim.x;
+                    const uint4 a0 = in[4u * idx], a1 = in[4u * idx + 1u], b0 = in[4u * idx + 2u], b1 = in[4u * idx + 3u];
+                    const uint32_t c0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    const uint32_t c1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                    uint32_t h[8];
+                    blake3_node(c0, c1, h);
+                    store_hash(tree_of<ILV>(a.layers, cw, r) + ((size_t)level_off(cw, lvl) + i) * NW, h);
+                    if (lvl == depth) store_hash(a.roots + (size_t)r * 8, h);
+                    out[2u * idx] = make_uint4(h[0], h[1], h[2], h[3]);
+                    out[2u * idx + 1u] = make_uint4(h[4], h[5], h[6], h[7]);
+                }
+                __syncthreads();  // (also drains this level's stores: the publication below needs them all in L2)
+                uint4 *t = in;
+                in = out;
+                out = t;
+            }
+            if (wave == 0u) publish(a, p_index, lane);
+            return;
+        }
+#endif
         after_hash(a, wave, lane, T);
     }
 
@@ -845,7 +894,8 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
         if (tid0 == 0 && a.stamps && round < kStampRec - 8) a.stamps[(size_t)kStampRec * blockIdx.x + 8 + round] = ph_t;
 #endif
     }
-    fin.after_loop(a, wave0, tid0 & 63u, T);
+    // (the t2 planes: the last row's entries have been read, every wave is past its hash phase after the barrier inside)
+    fin.after_loop(a, wave0, tid0 & 63u, T, smem + 512, (uint32_t)(E * PS * 12u));
     stamp_clock(a, 1);
 #ifdef ZIPK_DEBUG_STAMPS
     if (tid0 == 0 && a.stamps) {
@@ -1071,7 +1121,7 @@ __global__ void __launch_bounds__(T, 4) raa_commit16_kernel(CommitArgs a) {
             cc.advance(round);
         }
     }
-    fin.after_loop(a, wave0, tid0 & 63u, T);
+    fin.after_loop(a, wave0, tid0 & 63u, T, smem + 512, (uint32_t)(E * PS * 9u));  // (t2lo + t2dh)
     stamp_clock(a, 1);
 }
 
