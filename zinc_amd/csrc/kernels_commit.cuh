@@ -146,6 +146,9 @@ __device__ __forceinline__ i128 block_exclusive_scan_i96(i128 total, i128 *wave_
 }
 
 __device__ __forceinline__ void store_hash(uint32_t *dst, const uint32_t (&h)[8]) {
+#ifdef ZIPK_EXP_NOSTORE  // timing experiment (tools/exp_hash_phase.sh): the kernel without its tree stores
+    if (h[0] != 0x12345678u || h[1] != 0x9ABCDEF0u) return;
+#endif
     uint4 *d = reinterpret_cast<uint4 *>(dst);
     d[0] = make_uint4(h[0], h[1], h[2], h[3]);
     d[1] = make_uint4(h[4], h[5], h[6], h[7]);
@@ -279,6 +282,9 @@ struct StridedLeaves {
         if (MASKED && !(smask & (1u << E0))) return;
         const uint32_t j = base + E0 * T + tid;
         const uint32_t s = (uint32_t)((int32_t)d2 >> 31);
+#ifdef ZIPK_EXP_NOSTORE
+        if (d0 != 0x12345678u || d1 != 0x9ABCDEF0u) return;
+#endif
         if (MODE == kStorePacked) {
             const uint32_t pos = pbase<E0>() + lanes_below(__builtin_amdgcn_ballot_w64(true));
             *reinterpret_cast<uint4 *>(pk_v + (size_t)pos * 64) = make_uint4(d0, d1, d2, s);
@@ -383,7 +389,11 @@ __device__ __forceinline__ void bfly_hash(Src &src, uint32_t (&h)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const uint32_t snd = up ? A[i] : B[i];
+#ifdef ZIPK_EXP_NOXCHG  // timing experiment: the butterfly without its lane exchanges (wrong trees)
+            const uint32_t rcv = snd ^ 0x5A5A5A5Au;
+#else
             const uint32_t rcv = __shfl_xor(snd, 1 << (LVL - 1), 64);
+#endif
             m[i] = up ? rcv : A[i];      // left child
             m[8 + i] = up ? B[i] : rcv;  // right child
         }
@@ -707,11 +717,15 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
     uint64_t *t2lo = reinterpret_cast<uint64_t *>(smem + 512);         // E planes of PS slots
     uint32_t *t2hi = reinterpret_cast<uint32_t *>(t2lo + E * PS);
     int64_t *rowbuf = reinterpret_cast<int64_t *>(t2hi + E * PS);
-    // The thread's permutation indices (packed: pi1 source index | pi2 LDS slot << 16).
-    // They are RE-READ EVERY ROW (64 bytes per thread from tables that live in L2, ~1.4 us per row): held across the
-    // hash phase their 8 registers -- with the entries, now read from LDS when their turn comes -- were what kept the
-    // kernel at 104-108 VGPRs; without them it needs 86, and 160 instead of 96 registers per SIMD lane are left to the
-    // kernels that run beside it (-DZIPK_PIDX_IN_REGISTERS: the round-2 form, for A/B runs).
+    // The thread's permutation indices (packed: pi1 source index | pi2 LDS slot << 16), loaded ONCE and held for the
+    // whole kernel: 8 registers, 93 VGPRs in all (96 allocated: 128 of a SIMD lane's 512 stay free for the two gather
+    // waves of 48 and the row combinations beside this kernel).  Round 3 re-read them every row to free those 8 registers
+    // (85 VGPRs, when a gather wave took 32 and the budget was tighter) -- but vmcnt counts in order, so the first use of
+    // the re-read indices waited for every store of the previous row's hash phase to be acknowledged, on the critical
+    // path of every row: a timing build without the stores runs 0.095 ms faster, and with the indices in registers the
+    // kernel takes 1.271 instead of 1.289 ms alone, 1.376-1.382 instead of 1.410-1.419 ms in the step, the step
+    // 1.528-1.537 instead of 1.564-1.574 ms (alternated four times).  (-DZIPK_PIDX_REREAD: the round-3 form, for A/B runs.)
+    // The unpacking is kept inside the row loop (`^ z`, an opaque 0): hoisted, it is 16 more registers (109).
     uint32_t pidx[E];
     auto load_pidx = [&](uint32_t t) {
 #pragma unroll
@@ -725,7 +739,7 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
             pidx[e] = v1 | (v2 << 16);
         }
     };
-#ifdef ZIPK_PIDX_IN_REGISTERS
+#ifndef ZIPK_PIDX_REREAD
     load_pidx(tid0);
 #endif
     // ... the lane's store mask under an opening hint ...
@@ -770,7 +784,7 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
 #ifdef ZIPK_DEBUG_STAMPS
         ph_t = wall_clock64();
 #endif
-        fin.top_of_row();
+        // (fin.top_of_row(): moved down, just before this row's last scan barrier -- see there)
         const uint32_t z = opaque_zero(row);
         const uint32_t tid = tid0 + z;
         const int64_t *in = a.evals + (size_t)row * row_len;
@@ -789,13 +803,13 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
         }
 
         i128 v[E];
-#ifndef ZIPK_PIDX_IN_REGISTERS
+#ifdef ZIPK_PIDX_REREAD
         load_pidx(tid);  // (`tid` is opaque: the loads stay inside the loop)
 #endif
         // ---- pass 1: repeat + permute(pi1) + accumulate ------------------------
         if (active) {
 #pragma unroll
-            for (int e = 0; e < E; e++) v[e] = (i128)rowbuf[pidx[e] & 0xFFFFu];
+            for (int e = 0; e < E; e++) v[e] = (i128)rowbuf[(pidx[e] ^ z) & 0xFFFFu];  // (^ opaque 0: the unpacking stays in the loop)
 #pragma unroll
             for (int e = 1; e < E; e++) v[e] += v[e - 1];
         } else {
@@ -819,7 +833,7 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
         if (active) {
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const uint32_t slot = pidx[e] >> 16;
+                const uint32_t slot = (pidx[e] ^ z) >> 16;
                 const uint64_t lo = t2lo[slot];
                 const int64_t hi = (int64_t)(int32_t)t2hi[slot];
                 v[e] = (i128)(((u128)(uint64_t)hi << 64) | lo);
@@ -850,6 +864,10 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
 #pragma unroll
             for (int k = 0; k < NPF; k++) rowbuf[k * T + tid] = nxt[k];
         }
+        // the stores of a chunk end that is still owed (its head, one row ago) must be in L2 before the oldest waves read
+        // them back after THIS row's hash phase: drained here, two scan passes after they were issued, the wait is for
+        // nothing -- at the top of the row (round 3) the last wave to arrive stood in it on the critical path
+        fin.top_of_row();
         lds_barrier();
         ZIPK_PH(ph_a);
 #ifdef ZIPK_EXP_SCANS_ONLY  // timing experiment (tools/exp_scans_only.sh): a row without its hash phase and chunk ends
