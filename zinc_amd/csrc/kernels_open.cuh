@@ -854,7 +854,15 @@ __global__ void __launch_bounds__(256) open_columns_lean_kernel(OpenColsArgs a) 
 // src/zip/pcs/utils.rs:163-176; write_merkle_proof, src/zip/pcs_transcript.rs:198-211.
 typedef uint32_t oc_u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool IMAGE>
+// WHOLE = 32 * P: a workgroup whose block is P whole passes of 32 rows (the case at every size the gather matters at) takes
+// a branch-free path -- per-lane pointers set up once, the loads of ALL its levels and passes issued back to back before
+// the first one is used.  (Round 4's first form predicated every load on `row in block && level < depth`: the compiler
+// then cannot tell that the load of the previous level has been consumed and puts `s_waitcnt vmcnt(0)` in front of the next
+// one's address arithmetic -- four dependent round trips per wave where one was meant.)  Any other block -- ragged
+// ends, single rows -- takes the general loop below it.
+typedef const oc_u32x4 __attribute__((address_space(1))) *oc_gptr;
+
+template <bool IMAGE, int P>
 __global__ void __launch_bounds__(256) open_columns_ilv_kernel(OpenColsArgs a) {
     extern __shared__ __align__(16) unsigned char img[];
     constexpr uint32_t K = 4;  // Int<4> column values (checked by zip_ctx_create)
@@ -910,6 +918,70 @@ __global__ void __launch_bounds__(256) open_columns_ilv_kernel(OpenColsArgs a) {
     }
     const uint32_t vrank = rk[0];
     const uint64_t hdr = __builtin_bswap64((uint64_t)d);
+    // (uniform over the workgroup; depth >= 12: every wave has its first three levels)
+    const bool whole = P > 0 && (r0 & 3u) == 0 && r1 - r0 == 32u * (uint32_t)P && d >= 12u;
+    if (whole) {
+        constexpr int PP = P > 0 ? P : 1;
+        const size_t g0 = (size_t)(r0 >> 2) + gi;  // this lane's group of four rows in pass 0
+        const uint8_t *ptr[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) ptr[j] = src_base[j] + g0 * src_gstride[j] + src_off[j] + sub * 16u;
+        const bool has3 = wave + 12u < d;
+        oc_u32x4 v[PP][4];
+#pragma unroll
+        for (int p = 0; p < PP; p++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) v[p][j] = *(oc_gptr)(ptr[j] + (size_t)p * 8 * src_gstride[j]);
+        if (has3) {
+#pragma unroll
+            for (int p = 0; p < PP; p++) v[p][3] = *(oc_gptr)(ptr[3] + (size_t)p * 8 * src_gstride[3]);
+        }
+        if (wave == 3u) {
+            // column values (open_z.rs:130-137): lane -> (row lane / 2 of the pass, half of the Int<4>)
+            oc_u32x4 e[PP];
+#pragma unroll
+            for (int p = 0; p < PP; p++) {
+                const uint32_t vrow = r0 + 32u * p + (lane >> 1);
+                e[p] = *(oc_gptr)(a.pk + (size_t)(vrow >> 2) * 4 * a.pk_stride + ((size_t)vrank * 4 + (vrow & 3u)) * 16);
+            }
+#pragma unroll
+            for (int p = 0; p < PP; p++) {
+                const uint32_t vrow = r0 + 32u * p + (lane >> 1);
+                const uint4 o = half ? make_uint4(e[p].w, e[p].w, e[p].w, e[p].w) : make_uint4(e[p].x, e[p].y, e[p].z, e[p].w);
+                *reinterpret_cast<uint4 *>(base + (size_t)vrow * 8 * K + half * 16) = o;
+            }
+        }
+        if (wave == 2u && lane < 32u) {
+#pragma unroll
+            for (int p = 0; p < PP; p++) {
+                if (IMAGE) *reinterpret_cast<uint64_t *>(img + (size_t)(32u * p + lane) * rec_bytes) = hdr;
+                else *reinterpret_cast<uint64_t *>(recs + (size_t)(r0 + 32u * p + lane) * rec_bytes) = hdr;
+            }
+        }
+        const uint32_t lrow = 4u * gi + (sub >> 1);  // row of the pass
+        auto put = [&](int p, int j) {
+            const uint32_t k = wave + 4u * j, rr = 32u * p + lrow;
+            const uint64_t lo = ((uint64_t)v[p][j].y << 32) | v[p][j].x, hi = ((uint64_t)v[p][j].w << 32) | v[p][j].z;
+            if (IMAGE) {
+                uint64_t *dst = reinterpret_cast<uint64_t *>(img + rr * rec_bytes + 8 + k * 32u + half * 16u);
+                dst[0] = lo;
+                dst[1] = hi;
+            } else {
+                oc_u128_a8 o;
+                o.x = lo;
+                o.y = hi;
+                *reinterpret_cast<oc_u128_a8 *>(recs + (size_t)(r0 + rr) * rec_bytes + 8 + k * 32u + half * 16u) = o;
+            }
+        };
+#pragma unroll
+        for (int p = 0; p < PP; p++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) put(p, j);
+        if (has3) {
+#pragma unroll
+            for (int p = 0; p < PP; p++) put(p, 3);
+        }
+    } else
     for (uint32_t rb = r0 & ~3u; rb < r1; rb += 32u) {
         const uint32_t row = rb + 4u * gi + (sub >> 1);
         const bool ok = row >= r0 && row < r1;

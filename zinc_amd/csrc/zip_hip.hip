@@ -1280,16 +1280,21 @@ int32_t run_open_columns(zip_commitment *c, const uint32_t *cols_dv, uint32_t n_
             a.rows_per_block = want;
             const dim3 grid(n_cols, (row_hi - row_lo + a.rows_per_block - 1) / a.rows_per_block), block(256);
             LaunchTimer t(ctx, "open_columns_kernel", st);
-            hipLaunchKernelGGL(open_columns_ilv_kernel<false>, grid, block, 0, st, a);
+            if (want == 64) hipLaunchKernelGGL((open_columns_ilv_kernel<false, 2>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((open_columns_ilv_kernel<false, 1>), grid, block, 0, st, a);
             HIP_TRY(ctx, hipGetLastError());
             return ZIP_OK;
         }
         a.rows_per_block = (rpb + 3u) & ~3u;
         const size_t lds = (size_t)a.rows_per_block * rec;
         const dim3 grid(n_cols, (row_hi - row_lo + a.rows_per_block - 1) / a.rows_per_block), block(256);
-        if (int32_t rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(open_columns_ilv_kernel<true>), lds)) return rc;
+        // (blocks of 32 / 64 whole rows take the kernel's branch-free path: P passes of 32 rows with all loads in flight)
+        const void *fn = a.rows_per_block == 64 ? reinterpret_cast<const void *>(open_columns_ilv_kernel<true, 2>)
+                                                : reinterpret_cast<const void *>(open_columns_ilv_kernel<true, 1>);
+        if (int32_t rc = ensure_dynamic_lds(ctx, fn, lds)) return rc;
         LaunchTimer t(ctx, "open_columns_kernel", st);
-        hipLaunchKernelGGL(open_columns_ilv_kernel<true>, grid, block, lds, st, a);
+        if (a.rows_per_block == 64) hipLaunchKernelGGL((open_columns_ilv_kernel<true, 2>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((open_columns_ilv_kernel<true, 1>), grid, block, lds, st, a);
         HIP_TRY(ctx, hipGetLastError());
         return ZIP_OK;
     }
@@ -2103,10 +2108,27 @@ static int32_t commit_impl(zip_ctx *ctx, const int64_t *evals, size_t n_evals, z
             // From 24 rounds (2^26: 32 rounds of the 16-entry kernel, whose chunk-end stage is full with two rows):
             // chunks of two rounds, at most 16 -- there the gathers have slack (each waits ~0.3 ms for its chunk) and
             // what ends a step is the last chunk's gather alone: 5.733 / 5.693 against 5.805 / 5.782 ms per step.
+            // Round 4, 12..23 rounds (the branch-free gather, kernels_open.cuh, takes ~50 us per round beside the commit
+            // kernel's ~86): the same number of chunks but DESCENDING -- a last chunk of two thirds of the base, what that
+            // leaves spread over the first ones: 4,4,3,3,2 at 2^24.  What ends a step is the last chunk's gather alone
+            // (29 us per round of 256 rows); the chunk before it must be gathered by the time the last one is published
+            // (50 n <= 86 m: 4,4,4,3,1 and 6,4,3,2,1 lose what they gain).  Alternated on one box, four times each:
+            // 1.480 / 1.485 / 1.495 / 1.543 against 1.510 / 1.528 / 1.528 / 1.579 ms for 3,3,3,3,4 (profiles/EXPERIMENTS.md).
             if (sched.empty() && !ctx->n_chunks && rounds >= 12) {
                 const uint32_t n = rounds >= 24 ? std::min(kRingChunks, rounds / 2) : std::min(8u, rounds / 3), base = rounds / n;
-                for (uint32_t k = 0; k + 1 < n; k++) sched.push_back(base);
-                sched.push_back(rounds - base * (n - 1));
+                if (rounds >= 24 || base < 3) {
+                    for (uint32_t k = 0; k + 1 < n; k++) sched.push_back(base);
+                    sched.push_back(rounds - base * (n - 1));
+                } else {
+                    const uint32_t last = base * 2 / 3;
+                    uint32_t extra = rounds - (base * (n - 1) + last);
+                    for (uint32_t k = 0; k + 1 < n; k++) {
+                        const uint32_t more = (extra + (n - 2 - k)) / (n - 1 - k);  // (the larger shares first)
+                        sched.push_back(base + more);
+                        extra -= more;
+                    }
+                    sched.push_back(last);
+                }
             }
         }
         uint64_t chunk_ends = 0;
