@@ -800,6 +800,10 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
             const int64_t *nin = a.evals + (size_t)(row + gridDim.x) * row_len;
 #pragma unroll
             for (int k = 0; k < NPF; k++) nxt[k] = nin[k * T + tid];
+#ifdef ZIPK_EXP_NONXT  // timing experiment: no prefetch of the next witness row (every row computes on stale data)
+#pragma unroll
+            for (int k = 0; k < NPF; k++) nxt[k] = (int64_t)(k + z);
+#endif
         }
 
         i128 v[E];
