@@ -480,6 +480,7 @@ struct ChunkFinisher {
     // what the workgroup still owes of a finished chunk (wave-uniform): the levels from p_lvl up and the publication
     bool pending = false;
     uint32_t p_first = 0, p_nrows = 0, p_lvl = 0, p_index = 0;
+    uint32_t p_base = 0;  // the level the deferred stages of every chunk but the last one start at
     uint32_t n_deferred = 0;  // chunks finished the deferred way so far (the flag counters count them)
     uint32_t *flags = nullptr;  // LDS, kFinisherFlagWords zeroed words
 
@@ -524,11 +525,26 @@ struct ChunkFinisher {
     // After the hash phase of the row that FOLLOWS a chunk end.  The oldest wave of every SIMD (waves 0..3) finishes a
     // hash phase ~45 us before the youngest (then it only waits at the next row's first barrier), and work added to a
     // hash phase issues at the SIMD's mixed rate (3.4 cycles per instruction) where a lone wave at a chunk end runs at
-    // its dependent-issue rate (6).  So the levels above the head's stage are paid here, spread over the SIMDs:
-    //   stage 0 (two levels)   waves 0..W-1 together, a quarter of the groups each -> flag 0
-    //   stage j >= 1           ONE wave, (j - 1) mod W, once stage j-1 has counted in on flag j-1 -> flag j
-    //   publication            the wave of the last stage.
-    // A waiting wave has finished its own part of stage 0 before it waits, so nobody waits for a waiter.
+    // its dependent-issue rate (6).  So EVERYTHING above the butterflies' last level is paid here (round 4: the head's
+    // stage too -- at the chunk end it cost a barrier that collapsed the waves' stagger and ~35 us per chunk), spread
+    // over the SIMDs, two levels per stage:
+    //   a stage with >= 64 groups per row   waves 0..W-1 together, a W-th of the groups each; each counts in on flag j
+    //   a smaller stage                     ONE wave (round robin), once stage j-1 has counted in on flag j-1 -> flag j
+    //   publication                         the wave of the last stage.
+    // A waiting wave has finished its own part of the stage before, so nobody waits for a waiter.
+    // The flags count up over the chunks: stage j of this chunk is complete at flag j == target(j) = what the chunks
+    // before added (they all started at level p_base, the kernel's first_level) + this chunk's own waves.
+    static __device__ __forceinline__ bool stage_wide(uint32_t cw, uint32_t lvl, uint32_t nl, uint32_t j) {
+        return j == 0u || (cw >> (lvl - 1u + nl)) >= 64u;
+    }
+    static __device__ __forceinline__ uint32_t stage_waves(uint32_t cw, uint32_t depth, uint32_t lvl0, uint32_t j, uint32_t W) {
+        const uint32_t lvl = lvl0 + 2u * j;
+        if (lvl > depth) return 0u;
+        return stage_wide(cw, lvl, depth - lvl >= 1u ? 2u : 1u, j) ? W : 1u;
+    }
+    __device__ __forceinline__ uint32_t target(uint32_t cw, uint32_t depth, uint32_t j, uint32_t W) const {
+        return (n_deferred - 1u) * stage_waves(cw, depth, p_base, j, W) + stage_waves(cw, depth, p_lvl, j, W);
+    }
     __device__ __forceinline__ void after_hash(const CommitArgs &a, uint32_t wave, uint32_t lane, uint32_t T) {
         if (!(HASH && pending)) return;
         pending = false;
@@ -537,15 +553,18 @@ struct ChunkFinisher {
         if (wave >= W) return;
         const uint32_t cw = a.cw, depth = 31u - __builtin_clz(cw);
         uint32_t lvl = p_lvl, j = 0, owner = 0;
+        bool wide = true;
         while (lvl <= depth) {
             const uint32_t nl = depth - lvl >= 1u ? 2u : 1u;
-            if (j == 0) {
+            wide = stage_wide(cw, lvl, nl, j);
+            if (wide) {
+                if (j) wait_for(flags + (j - 1u), target(cw, depth, j - 1u, W));
                 upper_stage<ILV>(a, p_first, p_nrows, lvl, nl, lane + 64u * wave, 64u * W);
-                signal(flags, lane);
+                signal(flags + j, lane);
             } else {
-                owner = (j - 1u) % W;
+                owner = j % W;
                 if (wave == owner) {
-                    wait_for(flags + (j - 1u), (j == 1u ? W : 1u) * n_deferred);
+                    wait_for(flags + (j - 1u), target(cw, depth, j - 1u, W));
                     upper_stage<ILV>(a, p_first, p_nrows, lvl, nl, lane, 64u);
                     signal(flags + j, lane);
                 }
@@ -553,8 +572,9 @@ struct ChunkFinisher {
             lvl += nl;
             j++;
         }
+        if (j == 0u || wide) owner = 0u;  // (no stage at all, or the last one was everybody's: wave 0 publishes)
         if (wave == owner) {
-            if (j == 1u) wait_for(flags, W * n_deferred);  // stage 0 was the last one: everybody's part of it
+            if (j && wide) wait_for(flags + (j - 1u), target(cw, depth, j - 1u, W));
             publish(a, p_index, lane);
         }
     }
@@ -629,15 +649,27 @@ struct ChunkFinisher {
         }
         const uint32_t cw = a.cw, depth = 31u - __builtin_clz(cw);
         const uint32_t first = cc.first, nrows_c = round - first + 1;
-        __syncthreads();  // every wave's nodes of level first_level - 1 are in L2
         uint32_t lvl = first_level;
+        // A chunk with a next row hands ALL its upper levels to after_hash() of that row: no barrier here, the waves keep
+        // their stagger (every wave drains its stores before the next row's last scan barrier: top_of_row()).  The LAST
+        // chunk (and a tree with nothing above the butterflies) pays the head's stage now, all lanes at work, and
+        // after_loop() the rest.  (-DZIPK_HEAD_AT_END: every chunk the round-3 way, for A/B runs.)
+#ifdef ZIPK_HEAD_AT_END
+        const bool now = true;
+#else
+        const bool now = last || lvl > depth;
+#endif
 #ifndef ZIPK_EXP_NOFINISH  // timing experiment (tools/wg_spread.py): what do the upper levels cost?
-        if (lvl <= depth) {  // the head: one stage with every lane at work
-            const uint32_t nl = depth - lvl >= 1u ? 2u : 1u;
-            upper_stage<ILV>(a, first, nrows_c, lvl, nl, tid, T);
-            lvl += nl;
+        if (now) {
+            __syncthreads();  // every wave's nodes of level first_level - 1 are in L2
+            if (lvl <= depth) {  // the head: one stage with every lane at work
+                const uint32_t nl = depth - lvl >= 1u ? 2u : 1u;
+                upper_stage<ILV>(a, first, nrows_c, lvl, nl, tid, T);
+                lvl += nl;
+            }
         }
 #else
+        __syncthreads();
         lvl = depth + 1;
 #endif
         if (depth == 0 && tid == 0) {  // a one-leaf tree: the root is the leaf hash
@@ -648,6 +680,7 @@ struct ChunkFinisher {
                 store_hash(a.roots + (size_t)r * 8, h);
             }
         }
+        if (!last) p_base = lvl;  // (every chunk but the last one starts its deferred stages at the same level)
         pending = true;
         p_first = first;
         p_nrows = nrows_c;
