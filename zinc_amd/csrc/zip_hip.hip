@@ -1588,7 +1588,12 @@ namespace {
 template <int FL, int K, int DEG>
 int32_t launch_sumcheck_round(zip_sumcheck *s, const SumcheckRoundArgs<FL> &a, uint32_t blocks, const FieldDev<FL> &fd) {
     zip_ctx *ctx = s->ctx;
-    const size_t lds = (size_t)256 * (DEG + 1) * FL * 8;
+    size_t lds = (size_t)256 * (DEG + 1) * FL * 8;
+    // (occupancy experiment, tools/exp_sumcheck_occupancy.py: extra dynamic LDS so that fewer workgroups fit a CU)
+    if (const char *pad = getenv("ZIP_HIP_SUMCHECK_LDS_PAD")) {
+        lds += (size_t)atoi(pad);
+        if (int32_t rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(sumcheck_round_kernel<FL, K, DEG>), lds)) return rc;
+    }
     // a big round runs as exactly the workgroups that are resident together (grid-stride loop inside): a grid of
     // 8 per CU with 3 resident left a third wave of workgroups two thirds full
     if (blocks > ctx->num_cus) {
