@@ -216,3 +216,49 @@ def test_round_begin_end_protocol(mods):
     assert np.array_equal(out, b.round(r))
     a.free()
     b.free()
+
+
+@pytest.mark.parametrize("quad", ["1", "2", "0"])
+@pytest.mark.parametrize("modulus,fl", [(BENCH_MODULUS, 4), (TEST_MODULUS_2, 2), (MOD_NO_SPARE, 4), (MOD_3LIMB, 3)])
+@pytest.mark.parametrize("K,nv", [(1, 1), (2, 2), (3, 3), (4, 9), (2, 13), (4, 12)])
+def test_degree_3_rounds_on_both_kernels(mods, monkeypatch, quad, modulus, fl, K, nv):
+    """The folding rounds of a degree-3 sumcheck run on sumcheck_round_quad_kernel (four lanes per hypercube point, one
+    evaluation point each; the quad shares the folded pairs) by default, every round with ZIP_HIP_SUMCHECK_QUAD=2, none
+    with =0 (the one-thread-per-point kernel): all give the oracle's messages, in one-launch rounds (<= 64 workgroups) and in
+    rounds with the separate reduction."""
+    cabi, pcs = mods
+    monkeypatch.setenv("ZIP_HIP_SUMCHECK_QUAD", quad)
+    f = orc.make_field(modulus, fl)
+    mles = _tables(f, fl, modulus, K, nv, seed=nv * 11 + K)
+    to = orc.new_transcript()
+    msgs_o, rand_o = orc.sumcheck_prove_product(f, mles, 3, to)
+    t = pcs.KeccakTranscript()
+    msgs, rand = pcs.sumcheck_prove_product(t, mles, 3, pcs.FieldConfig(modulus, fl))
+    assert np.array_equal(msgs, msgs_o) and np.array_equal(rand, rand_o)
+
+
+@pytest.mark.parametrize("quad", ["1", "2", "0"])
+def test_ccs_sumcheck_2pow18_device_tables_on_both_kernels(mods, monkeypatch, quad):
+    """ZincProver's first sumcheck shape -- (M0 z * M1 z - M2 z) * eq, degree 3, four tables in HBM -- at 2^18: every round
+    message equals the oracle's, the caller's tables are only read."""
+    torch = pytest.importorskip("torch")
+    cabi, pcs = mods
+    monkeypatch.setenv("ZIP_HIP_SUMCHECK_QUAD", quad)
+    nv, fl, K = 18, 4, 4
+    f = orc.make_field(BENCH_MODULUS, fl)
+    rng = np.random.default_rng(18)
+    mles = rng.integers(0, 1 << 62, size=(K, 1 << nv, fl), dtype=np.uint64)
+    mles[..., fl - 1] >>= np.uint64(6)
+    R = 1 << (64 * fl)
+    c = [1 * R % BENCH_MODULUS, (BENCH_MODULUS - 1) * R % BENCH_MODULUS]
+    to = orc.new_transcript()
+    msgs_o, rand_o = orc.sumcheck_prove(f, mles, 3, [0b011, 0b100], c, to)
+    dev = [torch.from_numpy(mles[k].view(np.int64)).cuda() for k in range(K)]
+    before = [d.clone() for d in dev]
+    sc = cabi.Sumcheck(dev, nv, 3, cabi.make_field(BENCH_MODULUS, fl), comb=cabi.make_comb([0b011, 0b100], orc.field_elems(c, fl)))
+    r = None
+    for i in range(nv):
+        assert np.array_equal(sc.round(r), msgs_o[i]), i
+        r = rand_o[i]
+    sc.free()
+    assert all(torch.equal(a, b) for a, b in zip(dev, before))
