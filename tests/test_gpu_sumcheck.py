@@ -238,6 +238,33 @@ def test_degree_3_rounds_on_both_kernels(mods, monkeypatch, quad, modulus, fl, K
 
 
 @pytest.mark.parametrize("quad", ["1", "2", "0"])
+@pytest.mark.parametrize("modulus,fl", [(BENCH_MODULUS, 4), (MOD_NO_SPARE, 4), (MOD_3LIMB, 3)])
+@pytest.mark.parametrize("K,nv", [(1, 2), (2, 9), (3, 13), (2, 18)])
+def test_degree_2_rounds_on_both_kernels(mods, monkeypatch, quad, modulus, fl, K, nv):
+    """Degree 2 (ZincProver's second sumcheck): the quad kernel with its fourth lane idle takes the folding rounds of at
+    most 2^16 points by default, every round with ZIP_HIP_SUMCHECK_QUAD=2, none with =0."""
+    torch = pytest.importorskip("torch")
+    cabi, pcs = mods
+    monkeypatch.setenv("ZIP_HIP_SUMCHECK_QUAD", quad)
+    f = orc.make_field(modulus, fl)
+    if nv <= 13:
+        mles = _tables(f, fl, modulus, K, nv, seed=nv * 13 + K)
+    else:
+        rng = np.random.default_rng(nv)
+        mles = rng.integers(0, 1 << 62, size=(K, 1 << nv, fl), dtype=np.uint64)
+        mles[..., fl - 1] >>= np.uint64(6 if fl == 4 else 4)
+    to = orc.new_transcript()
+    msgs_o, rand_o = orc.sumcheck_prove_product(f, mles, 2, to)
+    dev = [torch.from_numpy(mles[k].view(np.int64)).cuda() for k in range(K)]
+    sc = cabi.Sumcheck(dev, nv, 2, cabi.make_field(modulus, fl))
+    r = None
+    for i in range(nv):
+        assert np.array_equal(sc.round(r), msgs_o[i]), i
+        r = rand_o[i]
+    sc.free()
+
+
+@pytest.mark.parametrize("quad", ["1", "2", "0"])
 def test_ccs_sumcheck_2pow18_device_tables_on_both_kernels(mods, monkeypatch, quad):
     """ZincProver's first sumcheck shape -- (M0 z * M1 z - M2 z) * eq, degree 3, four tables in HBM -- at 2^18: every round
     message equals the oracle's, the caller's tables are only read."""

@@ -357,11 +357,12 @@ __device__ __forceinline__ uint64_t quad_bcast(uint64_t x) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-template <int FL, int K>
+template <int FL, int K, int DEG = 3>
 __global__ void __launch_bounds__(256, 4) sumcheck_round_quad_kernel(SumcheckRoundArgs<FL> a, FieldDev<FL> f) {
+    static_assert(DEG == 2 || DEG == 3, "a quad holds the points 0..3: degree 3, or degree 2 with its fourth lane idle");
     extern __shared__ __align__(16) unsigned char sc_smem[];
     uint64_t *red = reinterpret_cast<uint64_t *>(sc_smem);  // [256][FL]
-    constexpr uint32_t ne = 4;
+    constexpr uint32_t ne = DEG + 1;  // (degree 2: lane 3 of a quad computes a fourth point nobody reads)
     const uint32_t tid = threadIdx.x, e = tid & 3u;
     uint64_t wacc[2 * FL + 1];
 #pragma unroll
@@ -459,7 +460,7 @@ __global__ void __launch_bounds__(256, 4) sumcheck_round_quad_kernel(SumcheckRou
         }
         __syncthreads();
     }
-    if (tid < ne * FL) a.partials[(size_t)blockIdx.x * ne * FL + tid] = red[tid];  // red[e][FL], e = 0..3
+    if (tid < ne * FL) a.partials[(size_t)blockIdx.x * ne * FL + tid] = red[tid];  // red[e][FL], e = 0..DEG
     sumcheck_last_block_folds<FL>(a, f, red, ne, tid);
 }
 

@@ -1587,7 +1587,7 @@ int32_t run_verify_fl(zip_ctx *ctx, const VerifyIn &in, const HostField &hf, std
 namespace {
 // degree 3: four lanes per hypercube point (sumcheck_round_quad_kernel, <= 128 VGPRs); ZIP_HIP_SUMCHECK_QUAD=0: the
 // one-thread-per-point kernel for every degree
-template <int FL, int K>
+template <int FL, int K, int DEG>
 int32_t launch_sumcheck_quad(zip_sumcheck *s, SumcheckRoundArgs<FL> a, const FieldDev<FL> &fd) {
     zip_ctx *ctx = s->ctx;
     const size_t lds = (size_t)256 * FL * 8;
@@ -1596,23 +1596,23 @@ int32_t launch_sumcheck_quad(zip_sumcheck *s, SumcheckRoundArgs<FL> a, const Fie
     if (blocks > ctx->num_cus) {  // (as below: exactly the workgroups that are resident together)
         static std::mutex mu;
         static std::map<std::pair<const void *, int>, int> occ;
-        const void *kern = reinterpret_cast<const void *>(sumcheck_round_quad_kernel<FL, K>);
+        const void *kern = reinterpret_cast<const void *>(sumcheck_round_quad_kernel<FL, K, DEG>);
         std::lock_guard<std::mutex> g(mu);
         int &per_cu = occ[std::make_pair(kern, ctx->device)];
         if (per_cu == 0 &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sumcheck_round_quad_kernel<FL, K>, 256, lds) != hipSuccess)
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sumcheck_round_quad_kernel<FL, K, DEG>, 256, lds) != hipSuccess)
             per_cu = 0;
         if (per_cu > 0) blocks = std::min<uint32_t>(blocks, ctx->num_cus * (uint32_t)per_cu);
     }
     a.done = blocks <= 64 ? s->done_d : nullptr;
     {
         LaunchTimer t(ctx, "sumcheck_round_kernel");
-        hipLaunchKernelGGL((sumcheck_round_quad_kernel<FL, K>), dim3(blocks), dim3(256), lds, ctx->stream, a, fd);
+        hipLaunchKernelGGL((sumcheck_round_quad_kernel<FL, K, DEG>), dim3(blocks), dim3(256), lds, ctx->stream, a, fd);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (!a.done) {
         LaunchTimer t(ctx, "sumcheck_reduce_kernel");
-        hipLaunchKernelGGL(sumcheck_reduce_kernel<FL>, dim3(1), dim3(256), 0, ctx->stream, a.partials, blocks, 4u, a.evals_out, fd,
+        hipLaunchKernelGGL(sumcheck_reduce_kernel<FL>, dim3(1), dim3(256), 0, ctx->stream, a.partials, blocks, (uint32_t)(DEG + 1), a.evals_out, fd,
                            a.host_flag, a.seq);
         HIP_TRY(ctx, hipGetLastError());
     }
@@ -1622,14 +1622,17 @@ int32_t launch_sumcheck_quad(zip_sumcheck *s, SumcheckRoundArgs<FL> a, const Fie
 template <int FL, int K, int DEG>
 int32_t launch_sumcheck_round(zip_sumcheck *s, const SumcheckRoundArgs<FL> &a, uint32_t blocks, const FieldDev<FL> &fd) {
     zip_ctx *ctx = s->ctx;
-    if constexpr (DEG == 3) {
-        // the FOLDING rounds (all but the first): there the quad kernel is as fast in the big rounds and up to 1.4x as
-        // fast in the small ones (four times the threads for the same number of points, five waves per SIMD instead of
-        // two); the first round has no fold to share and pays the point values four times over (1.99 against 1.45 ms at
-        // 2^24): it stays on the one-thread-per-point kernel.  ZIP_HIP_SUMCHECK_QUAD=0 / 2: never / every round.
+    if constexpr (DEG == 3 || DEG == 2) {
+        // Degree 3, the FOLDING rounds (all but the first): there the quad kernel is as fast in the big rounds and up to
+        // 1.4x as fast in the small ones (four times the threads for the same number of points, five waves per SIMD
+        // instead of two); the first round has no fold to share and pays the point values four times over (1.99 against
+        // 1.45 ms at 2^24): it stays on the one-thread-per-point kernel.  Degree 2 (ZincProver's second sumcheck) leaves
+        // the fourth lane of a quad idle: slower in the big rounds (0.96 against 0.57 ms in round 2 of 2^24), faster from
+        // 2^16 points down (the last rounds: 32 against 49 us).  ZIP_HIP_SUMCHECK_QUAD=0 / 2: never / every round.
         const char *knob = getenv("ZIP_HIP_SUMCHECK_QUAD");  // (per call: the tests flip it)
         const int mode = knob ? atoi(knob) : 1;
-        if (mode == 2 || (mode == 1 && a.fold)) return launch_sumcheck_quad<FL, K>(s, a, fd);
+        const bool pays = a.fold && (DEG == 3 || a.half <= 65536u);
+        if (mode == 2 || (mode == 1 && pays)) return launch_sumcheck_quad<FL, K, DEG>(s, a, fd);
     }
     size_t lds = (size_t)256 * (DEG + 1) * FL * 8;
     // (occupancy experiment, tools/exp_sumcheck_occupancy.py: extra dynamic LDS so that fewer workgroups fit a CU)
