@@ -23,8 +23,8 @@ python3 tools/pmc_summary.py --tag "$TAG" --trace $OUT/trace --bench-log $OUT/be
 python3 tools/pmc_summary.py --tag "$TAG" --name-suffix _nohint --trace $OUT/trace_nohint --bench-log $OUT/bench_trace_nohint.log
 python3 tools/pmc_summary.py --tag "$TAG" --name-suffix _2pow26 --trace $OUT/trace26 --bench-log $OUT/bench_trace26.log
 python3 tools/pmc_summary.py --tag "$TAG" --name-suffix _2pow20 --trace $OUT/trace20 --bench-log $OUT/bench_trace20.log
-python3 tools/timeline.py $OUT/trace -5 > $OUT/timeline24.txt 2>&1 || true
-python3 tools/timeline.py $OUT/trace20 -5 > $OUT/timeline20.txt 2>&1 || true
+python3 tools/timeline.py $OUT/trace median > $OUT/timeline24.txt 2>&1 || true
+python3 tools/timeline.py $OUT/trace20 median > $OUT/timeline20.txt 2>&1 || true
 # counter collection serialises kernel dispatch (no commit/open pipelining in these passes): one chunk
 export ZIP_HIP_CHUNKS=1
 for NV in 24 26; do

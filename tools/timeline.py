@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-step kernel timeline from a rocprofv3 --kernel-trace CSV directory (GPU box or here):
    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline
-   python3 tools/timeline.py gpurun_out/tl [step_index]
+   python3 tools/timeline.py gpurun_out/tl [step_index | median]
 Prints, for one commit+open step, every kernel's start / end relative to the start of the step's commit kernel."""
 import csv
 import glob
@@ -10,7 +10,7 @@ import sys
 
 def main():
     d = sys.argv[1]
-    which = int(sys.argv[2]) if len(sys.argv) > 2 else -2
+    arg = sys.argv[2] if len(sys.argv) > 2 else "-2"
     files = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)
     rows = []
     for f in files:
@@ -22,6 +22,12 @@ def main():
     if not starts:
         print("no commit kernel in trace")
         return
+    if arg == "median":  # the step whose commit kernel has the median duration among the last 20 (a typical steady step)
+        tail = starts[-21:-1] if len(starts) > 21 else starts[:-1] or starts
+        by_dur = sorted(tail, key=lambda i: rows[i][1] - rows[i][0])
+        which = starts.index(by_dur[len(by_dur) // 2]) - len(starts)
+    else:
+        which = int(arg)
     i0 = starts[which]
     i1 = starts[which + 1] if which + 1 < 0 and which + 1 + len(starts) < len(starts) else len(rows)
     try:
