@@ -549,7 +549,14 @@ struct ChunkFinisher {
         if (!(HASH && pending)) return;
         pending = false;
         n_deferred++;
-        const uint32_t W = T >= 256u ? 4u : (T + 63u) / 64u;
+        // the finishing waves: the TWO oldest of every SIMD (waves 0..7 of a 1024-thread workgroup).  Four (round 3) leave
+        // the oldest wave of a SIMD with 12 + 3 compressions per lane and chunk and the load latencies between them --
+        // more than its ~45 us lead: it became the last wave of that row; twelve or sixteen take the work to the
+        // youngest waves, which have no lead to spend (step 1.477 with 8 against 1.491 / 1.527 / 1.544 ms with 4 / 12 / 16).
+#ifndef ZIPK_FIN_WAVES
+#define ZIPK_FIN_WAVES 8u
+#endif
+        const uint32_t W = T >= 64u * ZIPK_FIN_WAVES ? ZIPK_FIN_WAVES : T >= 256u ? 4u : (T + 63u) / 64u;
         if (wave >= W) return;
         const uint32_t cw = a.cw, depth = 31u - __builtin_clz(cw);
         uint32_t lvl = p_lvl, j = 0, owner = 0;
