@@ -404,17 +404,18 @@ __device__ __forceinline__ void bfly_hash(Src &src, uint32_t (&h)[8]) {
 
 // ---- end of a chunk of rows of one workgroup of a persistent commit kernel --------------------------------------
 // The butterflies leave level `first_level - 1` of every row in global memory; what remains are the levels
-// first_level .. depth of the chunk's rows, the roots, and the publication of the chunk.  Round-2 did all of it at
+// first_level .. depth of the chunk's rows, the roots, and the publication of the chunk.  Round 2 did all of it at
 // the chunk end, level by level with a barrier each: 47 us per chunk of four rows at 2^24 (a quarter useful work, the
 // rest a chain of ten dependent compressions by ever fewer lanes, the release fence and the re-start of the row
-// pipeline), 13 % of the kernel (profiles/round3_wg_spread.md).  Now:
-//   head   at the chunk end, all waves: ONE stage of two levels, every lane hashing the complete 4-leaf subtree over
-//          four consecutive nodes (three compressions, no exchange between lanes).  For cw = 8192 and chunks of four
-//          rows it keeps every lane busy: useful work at the full rate.
-//   rest   the remaining levels (6 .. depth), the roots, the release fence and the counter: AFTER the hash phase of
-//          the NEXT row, by the oldest wave of each SIMD (ChunkFinisher::after_hash); the chunk is published ~70 us
-//          later than before, which the consumer's slack absorbs.  The last chunk of the kernel has no next row: its
-//          rest runs at once, the same way.
+// pipeline), 13 % of the kernel (profiles/round3_wg_spread.md); round 3 kept one stage of two levels ("the head") at
+// the chunk end behind a barrier.  Now (round 4) a chunk end with a next row does NOTHING at the chunk end:
+//   stages  of two levels each -- every lane hashing the complete 4-leaf subtree over four consecutive nodes (three
+//           compressions, no exchange between lanes) -- AFTER the hash phase of the NEXT row, by the two oldest waves of
+//           each SIMD (ChunkFinisher::after_hash): they finish a hash phase ~45 / ~30 us before the youngest and would
+//           only wait at the next barrier.  The chunk is published ~60-70 us after its last row, which the consumer's
+//           slack absorbs.
+//   last    the LAST chunk of the kernel has no next row: one stage at once with every lane (chunk_end), then the levels
+//           above it one by one through LDS (after_loop).
 // Stages hand their nodes over through global memory (L2): a storing wave waits for its stores (vmcnt(0)) before the
 // barrier or the LDS counter that the loading wave passes afterwards.
 // Levels [lvl, lvl + nl) (nl = 1 or 2) of the rows of rounds first .. first + nrows_c - 1 of this workgroup from their
