@@ -4,7 +4,7 @@
 # prints per run: ms/step, commit kernel (in step), gather sum, combine, wait
 NV=${NV:-24}
 REPS=${1:-3}
-OLD=${2:-zinc_amd/lib/libzip_hip_r3.so}
+OLD=${2:-zinc_amd/lib/libzip_hip_prev.so}
 one() {  # label, env...
     local label=$1; shift
     env "$@" python3 bench.py --num-vars $NV --no-cpu-baseline --no-pipelined --steps 20 --warmup 5 2>/dev/null | python3 -c "
