@@ -146,7 +146,7 @@ __device__ __forceinline__ i128 block_exclusive_scan_i96(i128 total, i128 *wave_
 }
 
 __device__ __forceinline__ void store_hash(uint32_t *dst, const uint32_t (&h)[8]) {
-#ifdef ZIPK_EXP_NOSTORE  // timing experiment (tools/exp_hash_phase.sh): the kernel without its tree stores
+#ifdef ZIPK_EXP_NOSTORE  // timing build (hipcc -DZIPK_EXP_NOSTORE -o other.so; ZIP_HIP_LIB_PATH=other.so tools/exp_scans_only.py or bench.py): the kernel without its tree stores
     if (h[0] != 0x12345678u || h[1] != 0x9ABCDEF0u) return;
 #endif
     uint4 *d = reinterpret_cast<uint4 *>(dst);
@@ -915,7 +915,7 @@ __global__ void __launch_bounds__(1024, 4) raa_commit_kernel(CommitArgs a) {
         fin.top_of_row();
         lds_barrier();
         ZIPK_PH(ph_a);
-#ifdef ZIPK_EXP_SCANS_ONLY  // timing experiment (tools/exp_scans_only.sh): a row without its hash phase and chunk ends
+#ifdef ZIPK_EXP_SCANS_ONLY  // timing build (-DZIPK_EXP_SCANS_ONLY, tools/exp_scans_only.py): a row without its hash phase and chunk ends
         if (tid0 == 0 && a.roots) a.roots[row * 8] = (uint32_t)t2lo[0];
         continue;
 #endif
