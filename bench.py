@@ -335,7 +335,16 @@ def main():
         proof = torch.empty(ctx.proof_len(n_cols, fl), dtype=torch.uint8, device=dev)
         roots_all = torch.empty((world * per, 32), dtype=torch.uint8, device=xdev) if world > 1 else None
 
+    # one proof after the other of the same shape into the same buffers: the call's arguments are marshalled once
+    # (cabi.commit_open_prepared; BENCH_PREPARED=0: through commit_open every step)
+    one_call = None
+    if not rows_mode and world == 1 and not (args.two_calls or args.no_hint) and os.environ.get("BENCH_PREPARED", "1") != "0":
+        one_call = ctx.commit_open_prepared(evals_d, coeffs, cols, q0, zf, proof)
+
     def step():
+        if one_call is not None:
+            one_call()
+            return
         if rows_mode:
             # hinted commit enqueued, the shard's open pipelined behind it, the roots all-gathered at the end
             com, _ = sharded.commit(evals_d, cols, gather_roots=False)

@@ -512,6 +512,41 @@ def test_commit_open_in_one_call_is_byte_identical(cabi, geometry, device_out, p
     assert none is None and np.array_equal(proof2, proof_o)
 
 
+@pytest.mark.parametrize("num_vars", [12, 18])
+def test_prepared_one_call_writes_the_same_proof_every_time(cabi, num_vars):
+    """cabi.commit_open_prepared: the zip_commit_open call with its arguments marshalled once (what bench.py's step is).
+    Called three times into a poisoned device buffer, with the witness replaced IN PLACE before the third call: the
+    oracle's proof bytes every time."""
+    torch = pytest.importorskip("torch")
+    nv = num_vars
+    z = orc.Zip(nv)
+    f = orc.make_field(BENCH_MODULUS, 4)
+    zf = cabi.make_field(BENCH_MODULUS, 4)
+    point = orc.point_to_field(f, np.arange(-7, nv - 7, dtype=np.int64))
+    lr = z.num_rows.bit_length() - 1
+    q0 = orc.build_eq_x_r(f, point[nv - lr:])
+    ctx = _ctx(cabi, z)
+    want = []
+    for seed in (31, 32):
+        evals = _witness(nv, seed=seed)
+        rows_o, layers_o, _ = z.commit(evals)
+        proof_o, cols, coeffs = z.open(f, evals, rows_o, layers_o, point, orc.new_transcript())
+        want.append((evals, proof_o, cols, coeffs))
+    assert np.array_equal(want[0][2], want[1][2]) and np.array_equal(want[0][3], want[1][3])  # (transcript-only inputs)
+    d_evals = torch.from_numpy(want[0][0].copy()).cuda()
+    out = torch.full((want[0][1].size,), 0xAA, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    call = ctx.commit_open_prepared(d_evals, want[0][3], want[0][2], q0, zf, out)
+    for k in range(3):
+        if k == 2:
+            d_evals.copy_(torch.from_numpy(want[1][0]))
+        out.fill_(0xAA)
+        torch.cuda.synchronize()
+        call()
+        ctx.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want[1 if k == 2 else 0][1]), k
+
+
 @pytest.mark.parametrize("num_vars", [16, 18, 20])
 @pytest.mark.parametrize("classes", ["1", "2", "4"])
 def test_single_round_commit_in_priority_classes(cabi, num_vars, classes, monkeypatch):

@@ -389,6 +389,30 @@ class ZipContext:
         self._check(rc, "zip_commit_open")
         return res, roots, (Commitment(self, h, True) if keep else None)
 
+    def commit_open_prepared(self, evals, coeffs, cols, q0_mont, field, out):
+        """The same zip_commit_open call as commit_open(..., out=out, want_roots=False, keep=False), with its arguments
+        marshalled ONCE: returns a function that makes the call (a prover that proves many witnesses of one shape into the
+        same buffers pays the numpy / ctypes conversions, ~10 us, once instead of per proof).  The arrays are kept alive by
+        the returned function; `evals` and `out` are read / written in place at every call."""
+        ptr, kind = _ptr(evals)
+        n = evals.size if isinstance(evals, np.ndarray) else evals.numel()
+        cols = np.ascontiguousarray(cols, dtype=np.uint32)
+        coeffs_c = np.ascontiguousarray(coeffs, dtype=np.int64) if coeffs is not None else None
+        q0 = np.ascontiguousarray(q0_mont, dtype=np.uint64) if q0_mont is not None else None
+        optr, okind = _ptr(out)
+        fn = lib().zip_commit_open
+        args = (self._h, ptr, n, kind, coeffs_c.ctypes.data if coeffs_c is not None else None, cols.ctypes.data, cols.size,
+                q0.ctypes.data if q0 is not None else None, C.byref(field), None, optr, okind, None)
+        keep = (evals, cols, coeffs_c, q0, field, out)
+        check = self._check
+
+        def call(_keep=keep):
+            rc = fn(*args)
+            if rc != ZIP_OK:
+                check(rc, "zip_commit_open")
+
+        return call
+
     def commit_open_begin(self, evals_d, coeffs, cols, q0_mont, field, out_d):
         """zip_commit_open_begin: the whole commit + open of a DEVICE witness into a DEVICE proof buffer is enqueued; the
         returned Job's wait() collects it.  Two jobs per ctx may be in flight."""
